@@ -1,0 +1,520 @@
+"""CPU oracle for the GDB-NeRF depth-guided bundle-sampling hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is the *checker*: a numpy float32 restatement of the
+reference algorithm (KLMAV-CUC/GDB-NeRF, `networks/gdb_nerf/{bundle_sampler,nerf,utils}.py`
+and `network.py:54-91`).  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py` may import it.  The product path (`gdb-nerf_amd/`) never does, and fails
+loudly when the HIP library is missing.
+
+Pinning status
+--------------
+* A1-A3 (`build_rays`, `sample`), A5 (`NeRF.forward`), the torch-`grid_sample` parts of A4
+  (per-ray RGB, voxel feature), the footprint level and the view-direction code are pinned
+  against outputs of the reference's own code, run in the authoring container by
+  `tests/golden/make_golden.py` (fixtures in `tests/golden/*.npz`).
+* The mip-mapped feature fetch (`nvdiffrast.torch.texture`, bundle_sampler.py:355-359) and the
+  two `nerfacc.volrend` calls (utils.py:35,110) live in un-vendored third-party CUDA packages
+  that are absent from the reference tree and from this image, with no version pinned by the
+  reference (README.md:14 names nvdiffrast without a version; nerfacc is not listed at all)
+  and no reference test pinning their results.  For those three ops: **parity unpinned** —
+  `texture_mip`, `weights_from_alpha` and `accumulate` below restate their published
+  semantics, and the reference's commented pure-torch variants (utils.py:46-85,112-115)
+  anchor the exclusive-cumprod / index_add structure.
+
+Everything is float32 (the reference never leaves fp32); the only integers are bundle indices
+and sample counts.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+F32 = np.float32
+PI32 = F32(math.pi)
+
+
+def _f(x) -> np.ndarray:
+    return np.asarray(x, dtype=F32)
+
+
+# ----------------------------------------------------------------------------------------
+# A1  BundleSampler.build_rays            (bundle_sampler.py:30-74)
+# ----------------------------------------------------------------------------------------
+def build_rays(tar_ext: np.ndarray, tar_int: np.ndarray, Ho: int, Wo: int) -> Dict[str, np.ndarray]:
+    """Pixel-centre rays of the target camera.
+
+    bundle_sampler.py:53-56 pixel centres (x+.5, y+.5) and uv = 2x/Wo-1, 2y/Ho-1;
+    :67-71 c2w = inverse(w2c), z_axis = c2w[:3,2], rays_o = c2w[:3,3],
+    rays_d = [x,y,1] (R_c2w K^-1)^T (not normalised); :74 pixel radius 1/sqrt(fx fy pi).
+    """
+    tar_ext, tar_int = _f(tar_ext), _f(tar_int)
+    B = tar_ext.shape[0]
+    xs = np.arange(Wo, dtype=F32) + F32(0.5)
+    ys = np.arange(Ho, dtype=F32) + F32(0.5)
+    gx, gy = np.meshgrid(xs, ys, indexing="xy")  # (Ho, Wo)
+    uv = np.stack((F32(2) * gx / F32(Wo) - F32(1), F32(2) * gy / F32(Ho) - F32(1)), axis=-1).astype(F32)
+    pix = np.stack((gx.ravel(), gy.ravel(), np.ones(Ho * Wo, dtype=F32)), axis=1)  # (Ho*Wo, 3)
+    c2w = np.linalg.inv(tar_ext).astype(F32)
+    kinv = np.linalg.inv(tar_int).astype(F32)
+    M = np.matmul(c2w[:, :3, :3], kinv).astype(F32)  # (B,3,3)
+    rays_d = np.matmul(pix[None], np.transpose(M, (0, 2, 1))).astype(F32).reshape(B, Ho, Wo, 3)
+    radius = (F32(1) / np.sqrt(tar_int[:, 0, 0] * tar_int[:, 1, 1] * PI32)).astype(F32)
+    return {
+        "rays_o": c2w[:, :3, 3].copy(),
+        "z_axis": c2w[:, :3, 2].copy(),
+        "rays_d": rays_d,
+        "uv": uv,
+        "tar_pixel_radius": radius,
+        "Ho": Ho,
+        "Wo": Wo,
+    }
+
+
+# ----------------------------------------------------------------------------------------
+# A2  BundleSampler._assemble_bundles      (bundle_sampler.py:76-120)
+# ----------------------------------------------------------------------------------------
+def assemble_bundles(rays: Dict[str, np.ndarray], depth_range: np.ndarray, vol_range: np.ndarray, b: int) -> Dict[str, np.ndarray]:
+    """Per-bundle record, kept as separate arrays instead of the reference's 23-float row.
+
+    :98-100 sub-ray directions in order (channel, by, bx); :99 mean direction;
+    :102 cos against the camera z axis; :104 mean uv; :106 disk radius b * pixel radius.
+    """
+    rd = rays["rays_d"]
+    B, Ho, Wo, _ = rd.shape
+    H, W = Ho // b, Wo // b
+    rd6 = rd.reshape(B, H, b, W, b, 3)
+    bundle_d = rd6.mean(axis=(2, 4), dtype=F32)  # (B,H,W,3)
+    sub_d = np.transpose(rd6, (0, 1, 3, 5, 2, 4)).reshape(B, H, W, 3, b * b)
+    z_axis = rays["z_axis"][:, None, None, :]
+    nrm = np.sqrt(np.sum(bundle_d * bundle_d, axis=-1, dtype=F32))
+    cos = (np.sum(bundle_d * z_axis, axis=-1, dtype=F32) / nrm).astype(F32)
+    uv = rays["uv"].reshape(H, b, W, b, 2).mean(axis=(1, 3), dtype=F32)
+    uv = np.broadcast_to(uv[None], (B, H, W, 2))
+    disk = np.broadcast_to((F32(b) * rays["tar_pixel_radius"]).astype(F32)[:, None, None], (B, H, W))
+    NB = B * H * W
+    return {
+        "o": np.broadcast_to(rays["rays_o"][:, None, None, :], (B, H, W, 3)).reshape(NB, 3),
+        "d": sub_d.reshape(NB, 3, b * b),
+        "uv": uv.reshape(NB, 2),
+        "near": _f(depth_range)[:, 0].reshape(NB),
+        "far": _f(depth_range)[:, 1].reshape(NB),
+        "vnear": _f(vol_range)[:, 0].reshape(NB),
+        "vfar": _f(vol_range)[:, 1].reshape(NB),
+        "disk": disk.reshape(NB),
+        "cos": cos.reshape(NB),
+        "B": B, "H": H, "W": W,
+    }
+
+
+# ----------------------------------------------------------------------------------------
+# A3  BundleSampler.sample                 (bundle_sampler.py:122-265)
+# ----------------------------------------------------------------------------------------
+def sample_counts(near: np.ndarray, far: np.ndarray, min_interval: np.ndarray, S_max: int, adaptive: bool) -> np.ndarray:
+    """:179 ceil(|far-near| / min_interval) clamped to [1, S_max]; :152 constant S otherwise."""
+    if not adaptive:
+        return np.full(near.shape, S_max, dtype=np.int32)
+    c = np.ceil(np.abs(far - near) / min_interval).astype(F32)
+    return np.clip(c, F32(1), F32(S_max)).astype(np.int32)
+
+
+def sample_bundles(rays: Dict[str, np.ndarray], depth_range: np.ndarray, vol_range: np.ndarray,
+                   near: np.ndarray, far: np.ndarray, b: int, S_max: int, global_num_depth: int,
+                   inv_depth: bool = False, adaptive: bool = False) -> Dict[str, np.ndarray]:
+    """Depth-guided sample placement for every bundle; bundle-major, sample-minor order.
+
+    :224-229 optional conversion to disparity and the minimum interval; :144/:183 bin edges
+    t_k = near + (far-near)/count * k; :246-247 mid-point and normalised volume depth;
+    :254-256 sub-ray points o + d z and their mean; :259-263 sphere radius.
+    """
+    depth_range, vol_range = _f(depth_range), _f(vol_range)
+    near, far = _f(near), _f(far)
+    if inv_depth:
+        depth_range = (F32(1) / depth_range).astype(F32)
+        vol_range = (F32(1) / vol_range).astype(F32)
+        min_iv = ((F32(1) / near - F32(1) / far) / F32(global_num_depth)).astype(F32)
+    else:
+        min_iv = ((far - near) / F32(global_num_depth)).astype(F32)
+    bd = assemble_bundles(rays, depth_range, vol_range, b)
+    B, H, W = bd["B"], bd["H"], bd["W"]
+    NB = B * H * W
+    min_iv_b = np.repeat(min_iv, H * W)
+    spb = sample_counts(bd["near"], bd["far"], min_iv_b, S_max, adaptive)
+    k = np.arange(S_max, dtype=np.int32)[None, :]
+    valid = k < spb[:, None]  # (NB, S_max)
+    cnt = spb.astype(F32)[:, None]
+    step = ((bd["far"] - bd["near"])[:, None] / cnt).astype(F32)
+    t0 = (bd["near"][:, None] + step * k.astype(F32)).astype(F32)
+    t1 = (bd["near"][:, None] + step * (k + 1).astype(F32)).astype(F32)
+    idx = np.broadcast_to(np.arange(NB, dtype=np.int64)[:, None], (NB, S_max))[valid]
+    t0, t1 = t0[valid], t1[valid]
+
+    z = (F32(0.5) * (t0 + t1)).astype(F32)
+    vn, vf = bd["vnear"][idx], bd["vfar"][idx]
+    d = (F32(2) * (z - vn) / (vf - vn) - F32(1)).astype(F32)
+    uvd = np.concatenate((bd["uv"][idx], d[:, None]), axis=1).astype(F32)
+    if inv_depth:
+        z = (F32(1) / z).astype(F32)
+    o = bd["o"][idx]  # (N,3)
+    rays_xyz = (o[:, :, None] + bd["d"][idx] * z[:, None, None]).astype(F32)  # (N,3,b*b)
+    centre = rays_xyz.mean(axis=-1, dtype=F32)
+    dist = np.sqrt(np.sum((centre - o) ** 2, axis=-1, dtype=F32)).astype(F32)
+    r, c = bd["disk"], bd["cos"]
+    tan = np.sqrt(np.maximum(F32(1) / (c * c) - F32(1), F32(1e-12))).astype(F32)
+    ball_unit = (r * c / np.sqrt((tan - r) ** 2 + F32(1))).astype(F32)
+    ball = (dist * ball_unit[idx]).astype(F32)
+    per_batch = spb.reshape(B, -1).sum(axis=1)
+    return {
+        "rays_xyz": rays_xyz, "uvd": uvd, "z_vals": z, "ball_radii": ball,
+        "indices": idx, "samples_per_batch": per_batch, "samples_per_bundle": spb,
+        "valid": valid,
+    }
+
+
+# ----------------------------------------------------------------------------------------
+# interpolation primitives used by A4
+# ----------------------------------------------------------------------------------------
+def _unnormalize(g: np.ndarray, size: int) -> np.ndarray:
+    """torch grid_sample, align_corners=False: ((g+1)*size-1)/2, then border clamp."""
+    x = (((g + F32(1)) * F32(size) - F32(1)) / F32(2)).astype(F32)
+    return np.minimum(np.maximum(x, F32(0)), F32(size - 1)).astype(F32)
+
+
+def bilinear_border(img: np.ndarray, gx: np.ndarray, gy: np.ndarray) -> np.ndarray:
+    """F.grid_sample(mode='bilinear', padding_mode='border', align_corners=False), 4-D case
+    (bundle_sampler.py:336).  img (C,H,W); gx, gy (N,) in [-1,1] -> (N,C)."""
+    C, H, W = img.shape
+    x, y = _unnormalize(gx, W), _unnormalize(gy, H)
+    x0f, y0f = np.floor(x), np.floor(y)
+    wx, wy = (x - x0f).astype(F32), (y - y0f).astype(F32)
+    x0, y0 = x0f.astype(np.int64), y0f.astype(np.int64)
+    x1, y1 = x0 + 1, y0 + 1
+    mx1, my1 = (x1 <= W - 1), (y1 <= H - 1)  # a tap past the edge contributes nothing
+    x1c, y1c = np.minimum(x1, W - 1), np.minimum(y1, H - 1)
+    ex, ey = (F32(1) - wx).astype(F32), (F32(1) - wy).astype(F32)
+    out = img[:, y0, x0] * (ex * ey)
+    out = out + img[:, y0, x1c] * (wx * ey * mx1)
+    out = out + img[:, y1c, x0] * (ex * wy * my1)
+    out = out + img[:, y1c, x1c] * (wx * wy * (mx1 & my1))
+    return out.T.astype(F32)
+
+
+def trilinear_border(vol: np.ndarray, gx: np.ndarray, gy: np.ndarray, gz: np.ndarray) -> np.ndarray:
+    """5-D grid_sample, trilinear/border/align_corners=False (bundle_sampler.py:322-324).
+    vol (C,D,H,W); grid x->W, y->H, z->D -> (N,C)."""
+    C, D, H, W = vol.shape
+    x, y, z = _unnormalize(gx, W), _unnormalize(gy, H), _unnormalize(gz, D)
+    x0f, y0f, z0f = np.floor(x), np.floor(y), np.floor(z)
+    wx, wy, wz = (x - x0f).astype(F32), (y - y0f).astype(F32), (z - z0f).astype(F32)
+    x0, y0, z0 = x0f.astype(np.int64), y0f.astype(np.int64), z0f.astype(np.int64)
+    out = np.zeros((C, gx.shape[0]), dtype=F32)
+    for dz in (0, 1):
+        zz = z0 + dz
+        mz = zz <= D - 1
+        fz = wz if dz else (F32(1) - wz)
+        for dy in (0, 1):
+            yy = y0 + dy
+            my = yy <= H - 1
+            fy = wy if dy else (F32(1) - wy)
+            for dx in (0, 1):
+                xx = x0 + dx
+                mx = xx <= W - 1
+                fx = wx if dx else (F32(1) - wx)
+                w = (fx * fy * fz * (mx & my & mz)).astype(F32)
+                out = out + vol[:, np.minimum(zz, D - 1), np.minimum(yy, H - 1), np.minimum(xx, W - 1)] * w
+    return out.T.astype(F32)
+
+
+def build_mips(tex: np.ndarray, max_level: int) -> List[np.ndarray]:
+    """Mip chain of a channel-last texture (V,H,W,C): level l is the 2x2 box average of
+    level l-1 (nvdiffrast mip construction).  Stops early at the first level whose extent
+    cannot be halved evenly; the number of levels built caps the usable mip level."""
+    levels = [_f(tex)]
+    for _ in range(max_level):
+        t = levels[-1]
+        V, H, W, C = t.shape
+        if H % 2 or W % 2 or H < 2 or W < 2:
+            break
+        t4 = t.reshape(V, H // 2, 2, W // 2, 2, C)
+        nxt = ((t4[:, :, 0, :, 0] + t4[:, :, 0, :, 1] + t4[:, :, 1, :, 0] + t4[:, :, 1, :, 1]) * F32(0.25)).astype(F32)
+        levels.append(nxt)
+    return levels
+
+
+def _tex_bilinear_clamp(t: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """One mip level, texel centres at (i+.5)/W, clamp-to-edge.  t (H,W,C); u,v in [0,1]."""
+    H, W, _ = t.shape
+    x = np.minimum(np.maximum(u * F32(W) - F32(0.5), F32(0)), F32(W - 1)).astype(F32)
+    y = np.minimum(np.maximum(v * F32(H) - F32(0.5), F32(0)), F32(H - 1)).astype(F32)
+    x0f, y0f = np.floor(x), np.floor(y)
+    fx, fy = (x - x0f).astype(F32)[:, None], (y - y0f).astype(F32)[:, None]
+    x0, y0 = x0f.astype(np.int64), y0f.astype(np.int64)
+    x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+    a00, a10, a01, a11 = t[y0, x0], t[y0, x1], t[y1, x0], t[y1, x1]
+    top = a00 + fx * (a10 - a00)
+    bot = a01 + fx * (a11 - a01)
+    return (top + fy * (bot - top)).astype(F32)
+
+
+def texture_mip(pyramid: List[np.ndarray], uv: np.ndarray, level: np.ndarray) -> np.ndarray:
+    """Restatement of `nvdiffrast.torch.texture(tex, uv, mip_level_bias=level,
+    boundary_mode='clamp', max_mip_level=L)` as called at bundle_sampler.py:355-359: no
+    uv derivatives, so the level is the bias alone, clamped to [0, L]; NaN and -inf fall to
+    level 0, +inf to L; linear-mipmap-linear filtering between floor(level) and the next
+    level.  PARITY UNPINNED (see module header).  pyramid[l] (V,H_l,W_l,C); uv (V,N,2);
+    level (V,N) -> (V,N,C)."""
+    L = len(pyramid) - 1
+    V, N, _ = uv.shape
+    C = pyramid[0].shape[-1]
+    lv = np.where(np.isnan(level), F32(0), level).astype(F32)
+    lv = np.minimum(np.maximum(lv, F32(0)), F32(L)).astype(F32)
+    l0 = np.floor(lv).astype(np.int64)
+    l1 = np.minimum(l0 + 1, L)
+    frac = (lv - l0.astype(F32)).astype(F32)
+    out = np.zeros((V, N, C), dtype=F32)
+    for v in range(V):
+        a = np.zeros((N, C), dtype=F32)
+        bq = np.zeros((N, C), dtype=F32)
+        for l in range(L + 1):
+            m0 = l0[v] == l
+            if m0.any():
+                a[m0] = _tex_bilinear_clamp(pyramid[l][v], uv[v, m0, 0], uv[v, m0, 1])
+            m1 = (l1[v] == l) & (frac[v] > 0)
+            if m1.any():
+                bq[m1] = _tex_bilinear_clamp(pyramid[l][v], uv[v, m1, 0], uv[v, m1, 1])
+        two = frac[v] > 0
+        res = a.copy()
+        res[two] = a[two] + frac[v][two, None] * (bq[two] - a[two])
+        out[v] = res
+    return out
+
+
+def _normalize(x: np.ndarray) -> np.ndarray:
+    """F.normalize(p=2, eps=1e-12)."""
+    n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    return (x / np.maximum(n, F32(1e-12))).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# A4  BundleSampler.encode                 (bundle_sampler.py:267-371)
+# ----------------------------------------------------------------------------------------
+def encode(src_images: np.ndarray, img_feat: np.ndarray, feat_volume: np.ndarray,
+           rays_xyz: np.ndarray, uvd: np.ndarray, ball_radii: np.ndarray,
+           src_exts: np.ndarray, src_ints: np.ndarray, tar_exts: np.ndarray,
+           samples_per_batch: np.ndarray, Ho: int, Wo: int, max_mip_level: int,
+           return_aux: bool = False):
+    """Multi-view fetch for every sample.
+
+    (i) :322-324 voxel feature; (ii) :327-337 per-sub-ray RGB, projected with the full-res
+    intrinsics and normalised by the *target* size; (iii) :340-348 footprint -> mip level;
+    (iv) :351-359 mip-mapped feature at the sphere centre (intrinsics / b, uv in [0,1]);
+    (v) :362-367 view-direction code.  Output channel order :369 [rgbs | feat | dir]."""
+    src_images, img_feat, feat_volume = _f(src_images), _f(img_feat), _f(feat_volume)
+    rays_xyz, uvd, ball_radii = _f(rays_xyz), _f(uvd), _f(ball_radii)
+    src_exts, src_ints, tar_exts = _f(src_exts), _f(src_ints), _f(tar_exts)
+    B, V, Cf, H, W = img_feat.shape
+    N, _, bb = rays_xyz.shape
+    b = int(round(math.sqrt(bb)))
+    tar_c = np.linalg.inv(tar_exts).astype(F32)[:, :3, 3]  # (B,3)
+    src_c = np.linalg.inv(src_exts).astype(F32)[..., :3, 3]  # (B,V,3)
+    centre_w = rays_xyz.mean(axis=-1, dtype=F32)  # (N,3)
+    Ks = src_ints.copy()
+    Ks[..., :2, :] = Ks[..., :2, :] / F32(b)
+    src_pix_r = (F32(1) / np.sqrt(Ks[:, :, 0, 0] * Ks[:, :, 1, 1] * PI32)).astype(F32)  # (B,V)
+
+    out = np.empty((V, N, 3 * bb + Cf + 4), dtype=F32)
+    vox = np.empty((N, feat_volume.shape[1]), dtype=F32)
+    lvl_all = np.empty((V, N), dtype=F32)
+    start = 0
+    for bi in range(B):
+        n = int(samples_per_batch[bi])
+        sl = slice(start, start + n)
+        vox[sl] = trilinear_border(feat_volume[bi], uvd[sl, 0], uvd[sl, 1], uvd[sl, 2])
+        pts = np.transpose(rays_xyz[sl], (0, 2, 1)).reshape(-1, 3)  # (n*bb,3) sample-major, sub-ray minor
+        ph = np.concatenate((pts, np.ones((pts.shape[0], 1), dtype=F32)), axis=1)
+        pyramid = build_mips(np.transpose(img_feat[bi], (0, 2, 3, 1)), max_mip_level)
+        uv_tex = np.empty((V, n, 2), dtype=F32)
+        for v in range(V):
+            cam = np.matmul(ph, src_exts[bi, v].T).astype(F32)[:, :3]
+            im = np.matmul(cam, src_ints[bi, v].T).astype(F32)
+            zc = np.maximum(im[:, 2], F32(1e-6))
+            gx = (F32(2) * (im[:, 0] / zc) / F32(Wo) - F32(1)).astype(F32)
+            gy = (F32(2) * (im[:, 1] / zc) / F32(Ho) - F32(1)).astype(F32)
+            rgb = bilinear_border(src_images[bi, v], gx, gy)  # (n*bb,3)
+            out[v, sl, :3 * bb] = np.transpose(rgb.reshape(n, bb, 3), (0, 2, 1)).reshape(n, 3 * bb)
+
+            ccam = cam.reshape(n, bb, 3).mean(axis=1, dtype=F32)  # sphere centre, camera frame
+            dist = np.sqrt(np.sum(ccam * ccam, axis=-1, dtype=F32)).astype(F32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sec2 = ((dist / ccam[:, 2]) ** 2).astype(F32)
+                a = np.sqrt(np.maximum((dist / ball_radii[sl]) ** 2 - F32(1), F32(1e-12))).astype(F32)
+                c = np.sqrt(np.maximum(sec2 - F32(1), F32(1e-12))).astype(F32)
+                proj_r = (sec2 / (a + c)).astype(F32)
+                lvl_all[v, sl] = np.log2(proj_r / src_pix_r[bi, v]).astype(F32)
+            cim = np.matmul(ccam, Ks[bi, v].T).astype(F32)
+            zc2 = np.maximum(cim[:, 2], F32(1e-6))
+            uv_tex[v, :, 0] = cim[:, 0] / zc2 / F32(W)
+            uv_tex[v, :, 1] = cim[:, 1] / zc2 / F32(H)
+
+            td = _normalize(centre_w[sl] - tar_c[bi][None])
+            sd = _normalize(centre_w[sl] - src_c[bi, v][None])
+            out[v, sl, 3 * bb + Cf:3 * bb + Cf + 3] = _normalize(td - sd)
+            out[v, sl, 3 * bb + Cf + 3] = np.sum(td * sd, axis=-1, dtype=F32)
+        out[:, sl, 3 * bb:3 * bb + Cf] = texture_mip(pyramid, uv_tex, lvl_all[:, sl])
+        start += n
+    if return_aux:
+        return out, vox, {"levels": lvl_all}
+    return out, vox
+
+
+# ----------------------------------------------------------------------------------------
+# A5  NeRF.forward                          (nerf.py:58-115)
+# ----------------------------------------------------------------------------------------
+def _linear(w: Dict[str, np.ndarray], name: str, x: np.ndarray) -> np.ndarray:
+    return (np.matmul(x, _f(w[name + ".weight"]).T) + _f(w[name + ".bias"])).astype(F32)
+
+
+def _relu(x: np.ndarray) -> np.ndarray:
+    return np.maximum(x, F32(0))
+
+
+def _softmax0(x: np.ndarray) -> np.ndarray:
+    m = x.max(axis=0, keepdims=True)
+    e = np.exp(x - m).astype(F32)
+    return (e / e.sum(axis=0, keepdims=True, dtype=F32)).astype(F32)
+
+
+def _softplus(x: np.ndarray) -> np.ndarray:
+    """nn.Softplus(beta=1, threshold=20)."""
+    with np.errstate(over="ignore"):
+        soft = np.log1p(np.exp(np.minimum(x, F32(20)))).astype(F32)
+    return np.where(x > F32(20), x, soft).astype(F32)
+
+
+def nerf_mlp(w: Dict[str, np.ndarray], vox_feat: np.ndarray, rgbs_feat_dir: np.ndarray,
+             feat_dim: int = 16, viewdir_agg: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """Radiance / density MLP over V source views.  State-dict names as in nerf.py:20-56.
+
+    nerf.py:98 the last feat_dim+3+4 channels feed the MLP; :69-71 view-direction add;
+    :73 unbiased variance and mean over views; :77-82 aggregation; :100-102 density;
+    :106-113 per-view blend weights applied to [rgbs | feat | rgb] and the 8-ch head."""
+    vox_feat, x_in = _f(vox_feat), _f(rgbs_feat_dir)
+    V = x_in.shape[0]
+    tail = feat_dim + 3 + 4
+    f = x_in[..., -tail:]
+    g = f[..., :-4]
+    if viewdir_agg:
+        g = (g + _relu(_linear(w, "view_fc.0", f[..., -4:]))).astype(F32)
+    mean = g.mean(axis=0, keepdims=True, dtype=F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        var = (np.sum((g - mean) ** 2, axis=0, keepdims=True, dtype=F32) / F32(V - 1)).astype(F32)
+    cat = np.concatenate((g, np.broadcast_to(var, g.shape), np.broadcast_to(mean, g.shape)), axis=-1)
+    G = _relu(_linear(w, "global_fc.0", cat))
+    a = _softmax0(_relu(_linear(w, "agg_w_fc.0", G)))
+    im = _relu(_linear(w, "fc.0", np.sum(G * a, axis=0, dtype=F32)))
+    h = np.concatenate((vox_feat, im), axis=-1)
+    x = _relu(_linear(w, "lr0.0", h))
+    sigma = _softplus(_linear(w, "sigma.0", x))[:, 0]
+    wf = np.concatenate((x, h), axis=-1)
+    wf = np.concatenate((np.broadcast_to(wf[None], (V,) + wf.shape), f), axis=-1)
+    bw = _softmax0(_relu(_linear(w, "weight.2", _relu(_linear(w, "weight.0", wf)))))
+    blended = np.sum(x_in[..., :-4] * bw, axis=0, dtype=F32)
+    feat = np.concatenate((blended, _relu(_linear(w, "feat_head.0", x))), axis=-1).astype(F32)
+    return sigma.astype(F32), feat
+
+
+# ----------------------------------------------------------------------------------------
+# A6  render_weight_from_density            (utils.py:19-43)
+# A7  accumulate_value_along_rays           (utils.py:88-121)
+# ----------------------------------------------------------------------------------------
+def weights_from_alpha(alpha: np.ndarray, indices: np.ndarray, n_bundles: int) -> np.ndarray:
+    """Restatement of nerfacc.volrend.render_weight_from_alpha: w_i = alpha_i * prod_{j<i in
+    the same bundle}(1 - alpha_j).  PARITY UNPINNED (module header)."""
+    out = np.empty_like(alpha)
+    T = F32(1)
+    prev = -1
+    for i in range(alpha.shape[0]):
+        if indices[i] != prev:
+            T = F32(1)
+            prev = indices[i]
+        out[i] = alpha[i] * T
+        T = F32(T * (F32(1) - alpha[i]))
+    return out
+
+
+def render_weights(sigma: np.ndarray, indices: np.ndarray, n_bundles: int) -> np.ndarray:
+    """utils.py:34 alpha = 1 - exp(-sigma) (no interval term); :35 transmittance weights;
+    :38-41 per-bundle normalisation by max(sum, 1e-6)."""
+    sigma = _f(sigma)
+    alpha = (F32(1) - np.exp(-sigma)).astype(F32)
+    w = weights_from_alpha(alpha, indices, n_bundles)
+    s = np.zeros(n_bundles, dtype=F32)
+    np.add.at(s, indices, w)
+    return (w / np.maximum(s[indices], F32(1e-6))).astype(F32)
+
+
+def accumulate(feat: np.ndarray, z_vals: np.ndarray, weights: np.ndarray, indices: np.ndarray,
+               n_bundles: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """utils.py:109-119: segmented sum of w * [feat | z | 1] per bundle (restates
+    nerfacc.volrend.accumulate_along_rays; PARITY UNPINNED)."""
+    vals = np.concatenate((_f(feat), _f(z_vals)[:, None], np.ones((feat.shape[0], 1), dtype=F32)), axis=1)
+    acc = np.zeros((n_bundles, vals.shape[1]), dtype=F32)
+    np.add.at(acc, indices, (vals * _f(weights)[:, None]).astype(F32))
+    return acc[:, :-2], acc[:, -2], acc[:, -1]
+
+
+def render_bundles(w: Dict[str, np.ndarray], rgbs_feat_dir: np.ndarray, vox_feat: np.ndarray,
+                   z_vals: np.ndarray, indices: np.ndarray, n_bundles: int, inv_depth: bool = False,
+                   feat_dim: int = 16, viewdir_agg: bool = True):
+    """Network.render_bundles, network.py:54-91."""
+    sigma, feat = nerf_mlp(w, vox_feat, rgbs_feat_dir, feat_dim, viewdir_agg)
+    wts = render_weights(sigma, indices, n_bundles)
+    z = _f(z_vals)
+    if inv_depth:
+        z = (F32(1) / z).astype(F32)
+    bf, depth, opac = accumulate(feat, z, wts, indices, n_bundles)
+    if inv_depth:
+        with np.errstate(divide="ignore"):
+            depth = (F32(1) / depth).astype(F32)
+    return bf, depth, opac
+
+
+# ----------------------------------------------------------------------------------------
+# A8  hot-path section of Network.forward   (network.py:145-172)
+# ----------------------------------------------------------------------------------------
+def hot_path(frame: Dict[str, np.ndarray], weights: Dict[str, np.ndarray], *, bundle_size: int = 2,
+             max_num_samples: int = 3, is_adaptive: bool = True, inv_depth: bool = False,
+             global_num_depth: int = 64, max_mipmap_level: int = 3, feat_dim: int = 16,
+             viewdir_agg: bool = True, return_intermediates: bool = False):
+    """build_rays -> sample -> encode -> render_bundles on one frame dict with keys
+    src_images (B,V,3,Ho,Wo), img_feat (B,V,C_f+3,H,W), feat_volume (B,C_v,D,H,W),
+    depth_range/vol_range (B,2,H,W), src_exts, src_ints, tar_ext, tar_int, near_far (B,2)."""
+    Ho, Wo = frame["src_images"].shape[-2:]
+    nf = _f(frame["near_far"])
+    rays = build_rays(frame["tar_ext"], frame["tar_int"], Ho, Wo)
+    smp = sample_bundles(rays, frame["depth_range"], frame["vol_range"], nf[:, 0], nf[:, 1],
+                         bundle_size, max_num_samples, global_num_depth, inv_depth, is_adaptive)
+    rfd, vox = encode(frame["src_images"], frame["img_feat"], frame["feat_volume"], smp["rays_xyz"],
+                      smp["uvd"], smp["ball_radii"], frame["src_exts"], frame["src_ints"],
+                      frame["tar_ext"], smp["samples_per_batch"], Ho, Wo, max_mipmap_level)
+    n_bundles = smp["samples_per_bundle"].shape[0]
+    bf, depth, opac = render_bundles(weights, rfd, vox, smp["z_vals"], smp["indices"], n_bundles,
+                                     inv_depth, feat_dim, viewdir_agg)
+    if return_intermediates:
+        return bf, depth, opac, {"rays": rays, "samples": smp, "rgbs_feat_dir": rfd, "vox_feat": vox}
+    return bf, depth, opac
+
+
+# ----------------------------------------------------------------------------------------
+# evaluator PSNR                            (evaluators/gdb_nerf.py:39,78-82)
+# ----------------------------------------------------------------------------------------
+def psnr(gt: np.ndarray, pred: np.ndarray, mask: np.ndarray | None = None) -> float:
+    """skimage peak_signal_noise_ratio(data_range=1) over masked pixels after clamp(0,1);
+    gt, pred (H,W,3); mask (H,W) bool."""
+    pred = np.clip(np.asarray(pred, dtype=np.float64), 0.0, 1.0)
+    gt = np.asarray(gt, dtype=np.float64)
+    if mask is not None:
+        gt, pred = gt[mask], pred[mask]
+    mse = float(np.mean((gt - pred) ** 2))
+    return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)

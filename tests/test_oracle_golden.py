@@ -1,0 +1,139 @@
+"""The oracle (oracle/gdb_oracle.py) against fixtures produced by the reference's own code
+(tests/golden/make_golden.py).  CPU only.  Tolerances are absolute, float32."""
+import numpy as np
+import pytest
+
+import gdb_oracle as oracle
+from conftest import frame_of, load_golden, max_abs, nerf_weights_of
+
+SAMPLE_CASES = {"fix6": (6, False, False), "ada3": (3, True, False),
+                "ada6inv": (6, True, True), "fix2inv": (2, False, True)}
+
+
+def test_build_rays_matches_reference():
+    fx = load_golden("F1_build_rays")
+    r = oracle.build_rays(fx["tar_ext"], fx["tar_int"], int(fx["Ho"]), int(fx["Wo"]))
+    for k in ("rays_o", "z_axis", "rays_d", "uv", "tar_pixel_radius"):
+        assert r[k].shape == fx[k].shape
+        assert max_abs(r[k], fx[k]) <= 1e-6, k
+
+
+@pytest.mark.parametrize("tag", list(SAMPLE_CASES))
+def test_sample_matches_reference(tag):
+    S, adaptive, inv = SAMPLE_CASES[tag]
+    fx = load_golden("F2_sample")
+    r = oracle.build_rays(fx["tar_ext"], fx["tar_int"], int(fx["Ho"]), int(fx["Wo"]))
+    s = oracle.sample_bundles(r, fx["depth_range"], fx["vol_range"], fx["near_far"][:, 0], fx["near_far"][:, 1],
+                              2, S, 64, inv, adaptive)
+    # integer work is exact: counts, compaction order
+    assert np.array_equal(s["samples_per_bundle"], fx[tag + "_samples_per_bundle"].astype(np.int32))
+    assert np.array_equal(s["indices"], fx[tag + "_indices"])
+    assert np.array_equal(s["samples_per_batch"], fx[tag + "_samples_per_batch"].astype(np.int64))
+    assert str(fx[tag + "_spb_dtype"]) == ("torch.float32" if adaptive else "torch.int32")  # reference dtype wart
+    assert max_abs(s["rays_xyz"], fx[tag + "_rays_xyz"]) <= 1e-4  # world mm, |x| ~ 1e3
+    assert max_abs(s["uvd"], fx[tag + "_uvd"]) <= 1e-6
+    assert max_abs(s["z_vals"], fx[tag + "_z_vals"]) <= 1e-4
+    assert max_abs(s["ball_radii"], fx[tag + "_ball_radii"]) <= 1e-5 * float(np.abs(fx[tag + "_ball_radii"]).max()) + 1e-7
+
+
+def test_sample_bundle_size_4():
+    fx = load_golden("F2_sample_b4")
+    r = oracle.build_rays(fx["tar_ext"], fx["tar_int"], int(fx["Ho"]), int(fx["Wo"]))
+    s = oracle.sample_bundles(r, fx["depth_range"], fx["vol_range"], fx["near_far"][:, 0], fx["near_far"][:, 1],
+                              4, 3, 64, False, True)
+    assert np.array_equal(s["indices"], fx["indices"])
+    assert s["rays_xyz"].shape == fx["rays_xyz"].shape == (s["indices"].shape[0], 3, 16)
+    assert max_abs(s["rays_xyz"], fx["rays_xyz"]) <= 1e-4
+    assert max_abs(s["uvd"], fx["uvd"]) <= 1e-6
+    assert max_abs(s["ball_radii"], fx["ball_radii"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name,viewdir", [("F3_nerf_V2", True), ("F3_nerf_V3", True), ("F3_nerf_V5", True),
+                                          ("F3_nerf_noviewdir", False)])
+def test_mlp_matches_reference(name, viewdir):
+    fx = load_golden(name)
+    sigma, feat = oracle.nerf_mlp(nerf_weights_of(fx), fx["vox_feat"], fx["rgbs_feat_dir"], 16, viewdir)
+    assert max_abs(sigma, fx["sigma"]) <= 2e-6
+    assert max_abs(feat, fx["feat"]) <= 2e-6
+
+
+@pytest.mark.parametrize("tag", ["dtu", "nerfinv", "mips"])
+def test_encode_matches_reference(tag):
+    fx = load_golden("F4_encode_" + tag)
+    Ho, Wo = fx["src_images"].shape[-2:]
+    rfd, vox, aux = oracle.encode(fx["src_images"], fx["img_feat"], fx["feat_volume"], fx["rays_xyz"], fx["uvd"],
+                                  fx["ball_radii"], fx["src_exts"], fx["src_ints"], fx["tar_ext"],
+                                  fx["samples_per_batch"], Ho, Wo, 3, return_aux=True)
+    ref = fx["rgbs_feat_dir"]
+    assert max_abs(rfd[..., :12], ref[..., :12]) <= 2e-6      # per-ray RGB: torch grid_sample, pinned
+    assert max_abs(rfd[..., 31:], ref[..., 31:]) <= 1e-5      # view-direction code, pinned
+    assert max_abs(vox, fx["vox_feat"]) <= 2e-6               # voxel feature: torch grid_sample, pinned
+    assert max_abs(aux["levels"], fx["tex_levels"]) <= 5e-6   # mip level handed to texture(), pinned
+    assert max_abs(rfd[..., 12:31], ref[..., 12:31]) <= 1e-5  # mip fetch: restatement on both sides (unpinned)
+    if tag == "mips":
+        lv = fx["tex_levels"]
+        assert lv.max() > 3.0 and (lv > 1.0).mean() > 0.3     # fixture exercises coarse levels + clamp
+
+
+@pytest.mark.parametrize("tag", ["dtu", "nerfinv", "mips"])
+def test_composite_and_hot_path(tag):
+    f5 = load_golden("F5_render_" + tag)
+    nb = int(f5["n_bundles"])
+    w = oracle.render_weights(f5["sigma"], f5["indices"], nb)
+    assert max_abs(w, f5["weights"]) <= 1e-6
+    inv = bool(f5["inv_depth"])
+    z = 1.0 / f5["z_vals"] if inv else f5["z_vals"]
+    bf, depth, opac = oracle.accumulate(f5["feat"], z, w, f5["indices"], nb)
+    if inv:
+        depth = 1.0 / depth
+    assert max_abs(bf, f5["bundle_feat"]) <= 2e-6
+    assert max_abs(depth, f5["depth"]) <= 1e-6 * float(np.abs(f5["depth"]).max())
+    assert max_abs(opac, f5["opacity"]) <= 1e-6
+
+    f6 = load_golden("F6_hotpath_" + tag)
+    bf, depth, opac, aux = oracle.hot_path(frame_of(f6), nerf_weights_of(f6), max_num_samples=int(f6["S_max"]),
+                                           is_adaptive=bool(f6["adaptive"]), inv_depth=bool(f6["inv_depth"]),
+                                           return_intermediates=True)
+    assert np.array_equal(aux["samples"]["samples_per_bundle"], f6["samples_per_bundle"].astype(np.int32))
+    assert max_abs(bf, f6["bundle_feat"]) <= 5e-6
+    assert max_abs(depth, f6["depth"]) <= 2e-6 * float(np.abs(f6["depth"]).max())
+    assert max_abs(opac, f6["opacity"]) <= 1e-6
+
+
+def test_texture_level_edge_cases():
+    """NaN / -inf fall to level 0, +inf to the coarsest level, exact integers use one level."""
+    rng = np.random.default_rng(0)
+    tex = rng.standard_normal((1, 8, 16, 3)).astype(np.float32)
+    pyr = oracle.build_mips(tex, 3)
+    assert [p.shape[1:3] for p in pyr] == [(8, 16), (4, 8), (2, 4), (1, 2)]
+    uv = rng.random((1, 6, 2)).astype(np.float32)
+    lv = np.array([[np.nan, -np.inf, np.inf, 0.0, 2.0, 7.5]], dtype=np.float32)
+    out = oracle.texture_mip(pyr, uv, lv)
+    z = np.zeros((1, 6), np.float32)
+    assert np.array_equal(out[0, 0], oracle.texture_mip(pyr, uv, z)[0, 0])
+    assert np.array_equal(out[0, 1], oracle.texture_mip(pyr, uv, z)[0, 1])
+    assert np.array_equal(out[0, 2], oracle.texture_mip(pyr, uv, z + 3)[0, 2])
+    assert np.array_equal(out[0, 5], oracle.texture_mip(pyr, uv, z + 3)[0, 5])
+    # odd extents stop the chain early and cap the level
+    pyr2 = oracle.build_mips(rng.standard_normal((1, 6, 10, 2)).astype(np.float32), 3)
+    assert len(pyr2) == 2
+
+
+def test_composite_edge_cases():
+    """Empty bundles stay zero; a fully transparent bundle hits the 1e-6 clamp."""
+    sigma = np.array([0.0, 0.0, 5.0, 1.0], np.float32)
+    idx = np.array([0, 0, 2, 2], np.int64)
+    w = oracle.render_weights(sigma, idx, 4)
+    assert np.all(w[:2] == 0) and abs(w[2:].sum() - 1) < 1e-6
+    bf, d, o = oracle.accumulate(np.ones((4, 3), np.float32), np.ones(4, np.float32), w, idx, 4)
+    assert np.all(bf[[0, 1, 3]] == 0) and np.all(o[[0, 1, 3]] == 0) and abs(o[2] - 1) < 1e-6
+
+
+def test_psnr():
+    rng = np.random.default_rng(0)
+    gt = rng.random((8, 8, 3))
+    assert oracle.psnr(gt, gt) == float("inf")
+    pred = gt + 0.1
+    m = np.ones((8, 8), bool)
+    expect = 10 * np.log10(1.0 / np.mean((gt - np.clip(pred, 0, 1)) ** 2))
+    assert abs(oracle.psnr(gt, pred, m) - expect) < 1e-9
