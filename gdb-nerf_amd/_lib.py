@@ -1,0 +1,81 @@
+"""ctypes binding of libgdbnerf_hip.so (C ABI: include/gdb_nerf_hip.h).
+
+There is no CPU fallback: if the shared library is missing or does not load, importing the
+operators raises.  Build it with `python gdb-nerf_amd/build.py` (or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgdbnerf_hip.so")
+
+GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
+GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 4, 8
+
+
+class GdbConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "bundle_size", "max_num_samples", "is_adaptive", "inv_depth", "global_num_depth",
+        "max_mipmap_level", "feat_dim", "voxel_dim", "hid_dim", "viewdir_agg")]
+
+
+class GdbFrame(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "V", "Ho", "Wo", "H", "W", "D")] + \
+               [(n, C.c_void_p) for n in (
+                   "d_src_images", "d_img_feat", "d_feat_volume", "d_depth_range", "d_vol_range",
+                   "d_src_exts", "d_src_ints", "d_tar_exts", "d_tar_ints", "d_near_far")]
+
+
+class GdbError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_CFG, _FRM = C.POINTER(GdbConfig), C.POINTER(GdbFrame)
+_SIGNATURES = {
+    "gdb_abi_version": (C.c_int, []),
+    "gdb_last_error": (C.c_char_p, []),
+    "gdb_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
+    "gdb_packed_weight_floats": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
+    "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
+    "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),
+    "gdb_build_rays": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P]),
+    "gdb_sample": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gdb_encode": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "gdb_mlp": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "gdb_composite": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdbError(f"{LIB_PATH} not found: the HIP hot path is not built "
+                           "(run `python gdb-nerf_amd/build.py`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.gdb_abi_version() != 1:
+            raise GdbError(f"ABI version {lib.gdb_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Status -> exception.  Bad arguments / shapes raise ValueError, as the reference's
+    Python operators do (bundle_sampler.py:220-221, network.py:33-34)."""
+    if rc == GDB_OK:
+        return
+    msg = load().gdb_last_error().decode("utf-8", "replace")
+    if rc in (GDB_E_BADARG, GDB_E_SHAPE):
+        raise ValueError(msg)
+    raise GdbError(f"[{rc}] {msg}")

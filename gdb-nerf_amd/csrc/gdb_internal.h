@@ -1,0 +1,199 @@
+// Internal layouts and device helpers shared by the HIP translation units.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gdb_nerf_hip.h"
+
+// ---- fixed network sizes (every config of the reference: dtu_pretrain.yaml:17-42) ----------
+#define GDB_CF 16            // fpn.feat_dims[feat_level]
+#define GDB_CFR (GDB_CF + 3) // feature ⊕ rgb channels of img_feat
+#define GDB_CP 20            // GDB_CFR padded to a multiple of 4 floats (16-B texel chunks)
+#define GDB_CV 8             // mvs.voxel_dim
+#define GDB_HID 64           // nerf.nerf_hidden_dims
+#define GDB_GF 32            // width of global_fc / agg
+#define GDB_IM 16            // width of fc
+#define GDB_HD (GDB_CV + GDB_IM)              // 24: [vox | im]
+#define GDB_FV (GDB_CFR + 4)                  // 23: per-view tail [feat | rgb | dir]
+#define GDB_W0IN (GDB_HID + GDB_HD + GDB_FV)  // 111
+
+// ---- camera block in the workspace ------------------------------------------------------
+// Per batch item: one target record, then V source records.
+#define TAR_STRIDE 24
+#define T_O 0      // rays_o (3)                      bundle_sampler.py:69
+#define T_Z 3      // camera z axis in world (3)      :68
+#define T_M 6      // R_c2w * K^-1, row-major 3x3     :70
+#define T_PIXR 15  // 1/sqrt(fx fy pi)                :74
+#define T_NEAR 16
+#define T_FAR 17
+#define T_MINIV 18 // minimum sample interval         :227-229
+#define T_DISK 19  // b * pixel radius                :106
+#define SRC_STRIDE 36
+#define S_E 0      // w2c rows 0..2 (3x4)
+#define S_K 12     // intrinsics 3x3
+#define S_KS 21    // intrinsics with rows 0,1 divided by b   :311-312
+#define S_C 30     // camera centre in world (3)              :305
+#define S_PIXR 33  // 1/sqrt(fx/b fy/b pi)                    :313
+
+
+// ---- packed MLP weights, fp32 section (float offsets; every block 4-float aligned) --------
+constexpr int pw_al(int x) { return (x + 3) / 4 * 4; }
+constexpr int PW_VIEW_W = 0;                                   // (19,4)
+constexpr int PW_VIEW_B = pw_al(PW_VIEW_W + GDB_CFR * 4);
+constexpr int PW_GLOB_W = pw_al(PW_VIEW_B + GDB_CFR);          // (32,57)
+constexpr int PW_GLOB_B = pw_al(PW_GLOB_W + GDB_GF * 3 * GDB_CFR);
+constexpr int PW_AGG_W = pw_al(PW_GLOB_B + GDB_GF);            // (1,32)
+constexpr int PW_AGG_B = pw_al(PW_AGG_W + GDB_GF);
+constexpr int PW_FC_W = pw_al(PW_AGG_B + 1);                   // (16,32)
+constexpr int PW_FC_B = pw_al(PW_FC_W + GDB_IM * GDB_GF);
+constexpr int PW_LR0_W = pw_al(PW_FC_B + GDB_IM);              // (64,24)
+constexpr int PW_LR0_B = pw_al(PW_LR0_W + GDB_HID * GDB_HD);
+constexpr int PW_SIG_W = pw_al(PW_LR0_B + GDB_HID);            // (1,64)
+constexpr int PW_SIG_B = pw_al(PW_SIG_W + GDB_HID);
+constexpr int PW_W0_W = pw_al(PW_SIG_B + 1);                   // (64,111)
+constexpr int PW_W0_B = pw_al(PW_W0_W + GDB_HID * GDB_W0IN);
+constexpr int PW_W2_W = pw_al(PW_W0_B + GDB_HID);              // (1,64)
+constexpr int PW_W2_B = pw_al(PW_W2_W + GDB_HID);
+constexpr int PW_FH_W = pw_al(PW_W2_B + 1);                    // (8,64)
+constexpr int PW_FH_B = pw_al(PW_FH_W + GDB_CV * GDB_HID);
+constexpr int PW_FP32_FLOATS = (PW_FH_B + GDB_CV + 63) / 64 * 64;
+
+struct WsLayout {
+    int levels;             // mip levels built beyond level 0 (<= max_mipmap_level)
+    int lvlH[GDB_MAX_MIP + 1], lvlW[GDB_MAX_MIP + 1];
+    size_t lvlOff[GDB_MAX_MIP + 1];  // float offset of each level inside one (b,v) pyramid
+    size_t pyrStride;                // floats per (b,v) pyramid
+    size_t camsOff, pyrOff, cntOff, offOff, bsumOff;  // byte offsets in the workspace
+    size_t total;
+    int nBlocksScan;
+};
+
+#define SCAN_BLOCK 1024
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
+    WsLayout L{};
+    L.lvlH[0] = f.H; L.lvlW[0] = f.W; L.lvlOff[0] = 0;
+    size_t acc = (size_t)f.H * f.W * GDB_CP;
+    int lv = 0;
+    while (lv < c.max_mipmap_level && lv < GDB_MAX_MIP) {
+        int h = L.lvlH[lv], w = L.lvlW[lv];
+        if (h < 2 || w < 2 || (h & 1) || (w & 1)) break;
+        ++lv;
+        L.lvlH[lv] = h / 2; L.lvlW[lv] = w / 2; L.lvlOff[lv] = acc;
+        acc += (size_t)(h / 2) * (w / 2) * GDB_CP;
+    }
+    L.levels = lv;
+    L.pyrStride = acc;
+    size_t nb = (size_t)f.B * f.H * f.W;
+    L.nBlocksScan = (int)((nb + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    size_t off = 0;
+    L.camsOff = off; off = align_up(off + sizeof(float) * (size_t)f.B * (TAR_STRIDE + (size_t)f.V * SRC_STRIDE), 256);
+    L.pyrOff = off;  off = align_up(off + sizeof(float) * L.pyrStride * f.B * f.V, 256);
+    L.cntOff = off;  off = align_up(off + sizeof(int32_t) * nb, 256);
+    L.offOff = off;  off = align_up(off + sizeof(int32_t) * nb, 256);
+    L.bsumOff = off; off = align_up(off + sizeof(int32_t) * (L.nBlocksScan + 1), 256);
+    L.total = off;
+    return L;
+}
+
+// Device-side view of one frame's prepared data.
+struct DevFrame {
+    int B, V, Ho, Wo, H, W, D, b;
+    int S_max, adaptive, inv_depth, levels;
+    int lvlH[GDB_MAX_MIP + 1], lvlW[GDB_MAX_MIP + 1];
+    unsigned lvlOff[GDB_MAX_MIP + 1];
+    unsigned pyrStride;
+    const float* cams;
+    const float* pyr;
+    const float* src_images;
+    const float* feat_volume;
+    const float* depth_range;
+    const float* vol_range;
+};
+
+static inline DevFrame dev_frame(const GdbConfig& c, const GdbFrame& f, const WsLayout& L, const void* ws) {
+    DevFrame d{};
+    d.B = f.B; d.V = f.V; d.Ho = f.Ho; d.Wo = f.Wo; d.H = f.H; d.W = f.W; d.D = f.D; d.b = c.bundle_size;
+    d.S_max = c.max_num_samples; d.adaptive = c.is_adaptive; d.inv_depth = c.inv_depth; d.levels = L.levels;
+    for (int i = 0; i <= GDB_MAX_MIP; ++i) { d.lvlH[i] = L.lvlH[i]; d.lvlW[i] = L.lvlW[i]; d.lvlOff[i] = (unsigned)L.lvlOff[i]; }
+    d.pyrStride = (unsigned)L.pyrStride;
+    d.cams = (const float*)((const char*)ws + L.camsOff);
+    d.pyr = (const float*)((const char*)ws + L.pyrOff);
+    d.src_images = f.d_src_images; d.feat_volume = f.d_feat_volume;
+    d.depth_range = f.d_depth_range; d.vol_range = f.d_vol_range;
+    return d;
+}
+
+#ifdef __HIPCC__
+// ---- device helpers -----------------------------------------------------------------------
+__device__ __forceinline__ const float* tar_cam(const DevFrame& f, int bi) {
+    return f.cams + (size_t)bi * (TAR_STRIDE + f.V * SRC_STRIDE);
+}
+__device__ __forceinline__ const float* src_cam(const DevFrame& f, int bi, int v) {
+    return tar_cam(f, bi) + TAR_STRIDE + v * SRC_STRIDE;
+}
+
+// Unnormalised ray direction of the pixel centre (x, y): [x, y, 1] * M^T.  bundle_sampler.py:70
+__device__ __forceinline__ void ray_dir(const float* __restrict__ M, float x, float y, float d[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = M[3 * i] * x + M[3 * i + 1] * y + M[3 * i + 2];
+}
+
+// torch grid_sample coordinate, align_corners=False, padding_mode='border'.
+__device__ __forceinline__ float gs_coord(float g, int size) {
+    float x = ((g + 1.f) * (float)size - 1.f) / 2.f;
+    return fminf(fmaxf(x, 0.f), (float)(size - 1));
+}
+
+// Per-bundle sample count.  bundle_sampler.py:152,179
+__device__ __forceinline__ int sample_count(float nearv, float farv, float min_iv, int S_max, int adaptive) {
+    if (!adaptive) return S_max;
+    float c = ceilf(fabsf(farv - nearv) / min_iv);
+    c = fminf(fmaxf(c, 1.f), (float)S_max);  // NaN -> 1 like torch.clamp? (clamp keeps NaN; counts of NaN are undefined upstream)
+    return (int)c;
+}
+
+// Sphere radius per unit distance.  bundle_sampler.py:262
+__device__ __forceinline__ float ball_unit(float disk, float cosv) {
+    float t = sqrtf(fmaxf(1.f / (cosv * cosv) - 1.f, 1e-12f)) - disk;
+    return disk * cosv / sqrtf(t * t + 1.f);
+}
+
+// Footprint -> mip level.  bundle_sampler.py:343-348
+__device__ __forceinline__ float mip_level(float cx, float cy, float cz, float ball, float src_pixr) {
+    float dist = sqrtf(cx * cx + cy * cy + cz * cz);
+    float q = dist / cz;
+    float sec2 = q * q;
+    float r = dist / ball;
+    float a = sqrtf(fmaxf(r * r - 1.f, 1e-12f));
+    float c = sqrtf(fmaxf(sec2 - 1.f, 1e-12f));
+    return log2f((sec2 / (a + c)) / src_pixr);
+}
+
+// nvdiffrast level selection with mip_level_bias only: clamp to [0, L]; NaN -> 0.
+__device__ __forceinline__ void mip_select(float level, int L, int& l0, int& l1, float& frac) {
+    float lv = fminf(fmaxf(level, 0.f), (float)L);  // fmaxf(NaN, 0) = 0
+    l0 = (int)floorf(lv);
+    l1 = min(l0 + 1, L);
+    frac = lv - (float)l0;
+}
+
+// Texel-space coordinate of one mip level with clamp-to-edge addressing.
+__device__ __forceinline__ void tex_coord(float u, int size, int& i0, int& i1, float& f) {
+    float x = fminf(fmaxf(u * (float)size - 0.5f, 0.f), (float)(size - 1));
+    float xf = floorf(x);
+    i0 = (int)xf;
+    i1 = min(i0 + 1, size - 1);
+    f = x - xf;
+}
+
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float t) {
+    return make_float4(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w));
+}
+
+__device__ __forceinline__ float softplus_t20(float x) {  // nn.Softplus(beta=1, threshold=20)
+    return x > 20.f ? x : log1pf(expf(x));
+}
+#endif

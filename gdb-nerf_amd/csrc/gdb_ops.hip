@@ -1,0 +1,641 @@
+// Operator mirrors of the GDB-NeRF hot path for gfx950: per-frame preparation (camera block,
+// feature mip pyramid) and one kernel family per reference method (build_rays, sample,
+// encode, NeRF.forward, composite).  These materialise the same intermediates as the
+// reference and exist for drop-in use of the individual operators and for bisecting the
+// fused kernel (gdb_fused.hip), which is the production path.
+//
+// Compiled with -ffp-contract=off: the reference evaluates every torch op separately, so
+// a*b+c is two roundings unless written as fmaf() here on purpose.
+#include "gdb_internal.h"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <cstdarg>
+
+// ============================================================================================
+// error plumbing
+// ============================================================================================
+static thread_local char g_err[512] = "";
+
+int gdb_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return gdb_fail(GDB_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCH_CHECK(name)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) return gdb_fail(GDB_E_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int gdb_abi_version(void) { return GDB_ABI_VERSION; }
+extern "C" const char* gdb_last_error(void) { return g_err; }
+
+int gdb_check_cfg(const GdbConfig* c) {
+    if (!c) return gdb_fail(GDB_E_BADARG, "cfg is NULL");
+    int b = c->bundle_size;
+    // network.py:33-34 raises ValueError('`Bundle size` must be a power of 2.')
+    if (b <= 0 || (b & (b - 1)) != 0) return gdb_fail(GDB_E_BADARG, "`Bundle size` must be a power of 2.");
+    if (b > 4) return gdb_fail(GDB_E_BADARG, "bundle_size %d unsupported (1, 2 or 4)", b);
+    if (c->max_num_samples < 1 || c->max_num_samples > GDB_MAX_SAMPLES)
+        return gdb_fail(GDB_E_BADARG, "max_num_samples %d outside 1..%d", c->max_num_samples, GDB_MAX_SAMPLES);
+    if (c->max_mipmap_level < 0 || c->max_mipmap_level > GDB_MAX_MIP)
+        return gdb_fail(GDB_E_BADARG, "max_mipmap_level %d outside 0..%d", c->max_mipmap_level, GDB_MAX_MIP);
+    if (c->global_num_depth < 1) return gdb_fail(GDB_E_BADARG, "global_num_depth must be positive");
+    if (c->feat_dim != GDB_CF || c->voxel_dim != GDB_CV || c->hid_dim != GDB_HID)
+        return gdb_fail(GDB_E_BADARG, "kernels are built for feat_dim %d, voxel_dim %d, nerf_hidden_dims %d (got %d, %d, %d)",
+                        GDB_CF, GDB_CV, GDB_HID, c->feat_dim, c->voxel_dim, c->hid_dim);
+    return GDB_OK;
+}
+
+int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs) {
+    if (!f) return gdb_fail(GDB_E_BADARG, "frame is NULL");
+    if (f->B < 1 || f->V < 1 || f->Ho < 1 || f->Wo < 1 || f->D < 1) return gdb_fail(GDB_E_SHAPE, "non-positive frame size");
+    if (f->V > GDB_MAX_VIEWS) return gdb_fail(GDB_E_SHAPE, "V=%d exceeds %d views", f->V, GDB_MAX_VIEWS);
+    if (f->Ho % c->bundle_size || f->Wo % c->bundle_size)
+        return gdb_fail(GDB_E_SHAPE, "image %dx%d not divisible by bundle_size %d", f->Ho, f->Wo, c->bundle_size);
+    if (f->H != f->Ho / c->bundle_size || f->W != f->Wo / c->bundle_size)
+        return gdb_fail(GDB_E_SHAPE, "bundle map %dx%d != image/bundle_size %dx%d", f->H, f->W, f->Ho / c->bundle_size, f->Wo / c->bundle_size);
+    if ((size_t)f->B * f->H * f->W * c->max_num_samples >= (size_t)1 << 31)
+        return gdb_fail(GDB_E_SHAPE, "more than 2^31 sample slots");
+    if (need_ptrs && (!f->d_src_images || !f->d_img_feat || !f->d_feat_volume || !f->d_depth_range || !f->d_vol_range ||
+                      !f->d_src_exts || !f->d_src_ints || !f->d_tar_exts || !f->d_tar_ints || !f->d_near_far))
+        return gdb_fail(GDB_E_BADARG, "frame has a NULL device pointer");
+    return GDB_OK;
+}
+
+extern "C" int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
+    if (!out_bytes) return gdb_fail(GDB_E_BADARG, "out_bytes is NULL");
+    *out_bytes = ws_layout(*cfg, *shape).total;
+    return GDB_OK;
+}
+
+// ============================================================================================
+// camera block
+// ============================================================================================
+template <int N>
+__device__ void invert_f64(const double* a, double* out) {  // Gauss-Jordan, partial pivoting
+    double m[N][2 * N];
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) { m[i][j] = a[i * N + j]; m[i][N + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        for (int r = c + 1; r < N; ++r) if (fabs(m[r][c]) > fabs(m[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 2 * N; ++j) { double t = m[c][j]; m[c][j] = m[p][j]; m[p][j] = t; }
+        double inv = 1.0 / m[c][c];
+        for (int j = 0; j < 2 * N; ++j) m[c][j] *= inv;
+        for (int r = 0; r < N; ++r) if (r != c) {
+            double fct = m[r][c];
+            for (int j = 0; j < 2 * N; ++j) m[r][j] -= fct * m[c][j];
+        }
+    }
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) out[i * N + j] = m[i][N + N * 0 + j];
+}
+
+__global__ void k_cam_prep(int B, int V, int b, int inv_depth, int gnd, const float* __restrict__ tar_exts,
+                           const float* __restrict__ tar_ints, const float* __restrict__ src_exts,
+                           const float* __restrict__ src_ints, const float* __restrict__ near_far,
+                           float* __restrict__ cams) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int per = V + 1;
+    if (t >= B * per) return;
+    int bi = t / per, v = t % per - 1;
+    float* tar = cams + (size_t)bi * (TAR_STRIDE + V * SRC_STRIDE);
+    const float PI_F = 3.14159265358979323846f;
+    if (v < 0) {
+        double E[16], Ei[16], K[9], Ki[9];
+        for (int i = 0; i < 16; ++i) E[i] = tar_exts[bi * 16 + i];
+        for (int i = 0; i < 9; ++i) K[i] = tar_ints[bi * 9 + i];
+        invert_f64<4>(E, Ei);
+        invert_f64<3>(K, Ki);
+        for (int i = 0; i < 3; ++i) { tar[T_O + i] = (float)Ei[i * 4 + 3]; tar[T_Z + i] = (float)Ei[i * 4 + 2]; }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;  // product of the float-rounded inverses, as the reference multiplies fp32 tensors
+                for (int k = 0; k < 3; ++k) s += (double)(float)Ei[i * 4 + k] * (double)(float)Ki[k * 3 + j];
+                tar[T_M + 3 * i + j] = (float)s;
+            }
+        float fx = tar_ints[bi * 9 + 0], fy = tar_ints[bi * 9 + 4];
+        float pr = 1.f / sqrtf(fx * fy * PI_F);
+        tar[T_PIXR] = pr;
+        float nr = near_far[bi * 2], fr = near_far[bi * 2 + 1];
+        tar[T_NEAR] = nr; tar[T_FAR] = fr;
+        tar[T_MINIV] = inv_depth ? (1.f / nr - 1.f / fr) / (float)gnd : (fr - nr) / (float)gnd;
+        tar[T_DISK] = (float)b * pr;
+        for (int i = T_DISK + 1; i < TAR_STRIDE; ++i) tar[i] = 0.f;
+    } else {
+        float* s = tar + TAR_STRIDE + v * SRC_STRIDE;
+        const float* Ef = src_exts + ((size_t)bi * V + v) * 16;
+        const float* Kf = src_ints + ((size_t)bi * V + v) * 9;
+        double E[16], Ei[16];
+        for (int i = 0; i < 16; ++i) E[i] = Ef[i];
+        invert_f64<4>(E, Ei);
+        for (int i = 0; i < 12; ++i) s[S_E + i] = Ef[i];
+        for (int i = 0; i < 9; ++i) { s[S_K + i] = Kf[i]; s[S_KS + i] = (i < 6) ? Kf[i] / (float)b : Kf[i]; }
+        for (int i = 0; i < 3; ++i) s[S_C + i] = (float)Ei[i * 4 + 3];
+        s[S_PIXR] = 1.f / sqrtf(s[S_KS + 0] * s[S_KS + 4] * PI_F);
+        s[34] = 0.f; s[35] = 0.f;
+    }
+}
+
+// ============================================================================================
+// feature pyramid: NCHW (B*V, C_f+3, H, W) -> channel-last, 20-float texels, + box mips
+// ============================================================================================
+// Level 0: one thread per (texel, 4-channel chunk).  Consecutive lanes walk x, so each of the
+// four channel-plane reads is a coalesced 256-B row segment; the write is one 16-B chunk.
+__global__ void k_pyr_level0(int BV, int C, int H, int W, unsigned pyrStride, const float* __restrict__ src,
+                             float* __restrict__ pyr) {
+    size_t n = (size_t)BV * (GDB_CP / 4) * H * W;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int x = (int)(t % W); size_t r = t / W;
+    int y = (int)(r % H); r /= H;
+    int chunk = (int)(r % (GDB_CP / 4)); int bv = (int)(r / (GDB_CP / 4));
+    const float* s = src + (size_t)bv * C * H * W + (size_t)y * W + x;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = chunk * 4 + i;
+        v[i] = c < C ? s[(size_t)c * H * W] : 0.f;
+    }
+    float4* dst = (float4*)(pyr + (size_t)bv * pyrStride + ((size_t)y * W + x) * GDB_CP + chunk * 4);
+    *dst = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Level l from level l-1: 2x2 box average, (a+b+c+d)*0.25, one thread per (texel, chunk).
+__global__ void k_pyr_down(int BV, int Hs, int Ws, unsigned pyrStride, unsigned offSrc, unsigned offDst,
+                           float* __restrict__ pyr) {
+    int Hd = Hs / 2, Wd = Ws / 2;
+    size_t n = (size_t)BV * Hd * Wd * (GDB_CP / 4);
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int chunk = (int)(t % (GDB_CP / 4)); size_t r = t / (GDB_CP / 4);
+    int x = (int)(r % Wd); r /= Wd;
+    int y = (int)(r % Hd); int bv = (int)(r / Hd);
+    const float* base = pyr + (size_t)bv * pyrStride + offSrc;
+    const float4 a = *(const float4*)(base + ((size_t)(2 * y) * Ws + 2 * x) * GDB_CP + chunk * 4);
+    const float4 b = *(const float4*)(base + ((size_t)(2 * y) * Ws + 2 * x + 1) * GDB_CP + chunk * 4);
+    const float4 c = *(const float4*)(base + ((size_t)(2 * y + 1) * Ws + 2 * x) * GDB_CP + chunk * 4);
+    const float4 d = *(const float4*)(base + ((size_t)(2 * y + 1) * Ws + 2 * x + 1) * GDB_CP + chunk * 4);
+    float4 o = make_float4((a.x + b.x + c.x + d.x) * 0.25f, (a.y + b.y + c.y + d.y) * 0.25f,
+                           (a.z + b.z + c.z + d.z) * 0.25f, (a.w + b.w + c.w + d.w) * 0.25f);
+    *(float4*)(pyr + (size_t)bv * pyrStride + offDst + ((size_t)y * Wd + x) * GDB_CP + chunk * 4) = o;
+}
+
+extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, true); if (rc) return rc;
+    if (!ws) return gdb_fail(GDB_E_BADARG, "workspace is NULL");
+    WsLayout L = ws_layout(*cfg, *f);
+    if (ws_bytes < L.total) return gdb_fail(GDB_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream_;
+    float* cams = (float*)((char*)ws + L.camsOff);
+    float* pyr = (float*)((char*)ws + L.pyrOff);
+    int ncam = f->B * (f->V + 1);
+    hipLaunchKernelGGL(k_cam_prep, dim3((ncam + 63) / 64), dim3(64), 0, st, f->B, f->V, cfg->bundle_size, cfg->inv_depth,
+                       cfg->global_num_depth, f->d_tar_exts, f->d_tar_ints, f->d_src_exts, f->d_src_ints, f->d_near_far, cams);
+    LAUNCH_CHECK("k_cam_prep");
+    int BV = f->B * f->V;
+    size_t n0 = (size_t)BV * (GDB_CP / 4) * f->H * f->W;
+    hipLaunchKernelGGL(k_pyr_level0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, BV, GDB_CFR, f->H, f->W,
+                       (unsigned)L.pyrStride, f->d_img_feat, pyr);
+    LAUNCH_CHECK("k_pyr_level0");
+    for (int l = 1; l <= L.levels; ++l) {
+        size_t n = (size_t)BV * L.lvlH[l] * L.lvlW[l] * (GDB_CP / 4);
+        hipLaunchKernelGGL(k_pyr_down, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, BV, L.lvlH[l - 1], L.lvlW[l - 1],
+                           (unsigned)L.pyrStride, (unsigned)L.lvlOff[l - 1], (unsigned)L.lvlOff[l], pyr);
+        LAUNCH_CHECK("k_pyr_down");
+    }
+    return GDB_OK;
+}
+
+// ============================================================================================
+// A1  build_rays (materialised, for the operator mirror)
+// ============================================================================================
+__global__ void k_build_rays(DevFrame f, float* __restrict__ rays_d, float* __restrict__ uv, float* __restrict__ rays_o,
+                             float* __restrict__ z_axis, float* __restrict__ pixr) {
+    size_t n = (size_t)f.B * f.Ho * f.Wo;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)f.B * 3) {
+        int bi = (int)(t / 3), i = (int)(t % 3);
+        rays_o[t] = tar_cam(f, bi)[T_O + i];
+        z_axis[t] = tar_cam(f, bi)[T_Z + i];
+        if (i == 0) pixr[bi] = tar_cam(f, bi)[T_PIXR];
+    }
+    if (t >= n) return;
+    int px = (int)(t % f.Wo); size_t r = t / f.Wo;
+    int py = (int)(r % f.Ho); int bi = (int)(r / f.Ho);
+    float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    float d[3];
+    ray_dir(tar_cam(f, bi) + T_M, x, y, d);
+    rays_d[t * 3 + 0] = d[0]; rays_d[t * 3 + 1] = d[1]; rays_d[t * 3 + 2] = d[2];
+    if (bi == 0) {
+        uv[((size_t)py * f.Wo + px) * 2 + 0] = 2.f * x / (float)f.Wo - 1.f;
+        uv[((size_t)py * f.Wo + px) * 2 + 1] = 2.f * y / (float)f.Ho - 1.f;
+    }
+}
+
+extern "C" int gdb_build_rays(const GdbConfig* cfg, const GdbFrame* f, const void* ws, float* rays_d, float* uv,
+                              float* rays_o, float* z_axis, float* pixr, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
+    if (!ws || !rays_d || !uv || !rays_o || !z_axis || !pixr) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    WsLayout L = ws_layout(*cfg, *f);
+    DevFrame d = dev_frame(*cfg, *f, L, ws);
+    size_t n = (size_t)f->B * f->Ho * f->Wo;
+    hipLaunchKernelGGL(k_build_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, d, rays_d, uv,
+                       rays_o, z_axis, pixr);
+    LAUNCH_CHECK("k_build_rays");
+    return GDB_OK;
+}
+
+// ============================================================================================
+// A2+A3  sample
+// ============================================================================================
+// Geometry of one bundle, shared by the mirror below and by the fused kernel.
+template <int BB>  // BB = b*b
+struct Bundle {
+    float o[3];
+    float d[BB][3];    // sub-ray directions, order by*b+bx            bundle_sampler.py:100
+    float u, v;        // mean normalised pixel coordinate              :104
+    float nearv, farv, vnear, vfar;
+    float unit;        // sphere radius per unit distance               :262
+    int count;
+};
+
+template <int BB>
+__device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
+    constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
+    const float* tc = tar_cam(f, bi);
+    float sum[3] = {0.f, 0.f, 0.f};
+    float su = 0.f, sv = 0.f;
+#pragma unroll
+    for (int by = 0; by < b; ++by)
+#pragma unroll
+        for (int bx = 0; bx < b; ++bx) {
+            float x = (float)(w * b + bx) + 0.5f, y = (float)(h * b + by) + 0.5f;
+            ray_dir(tc + T_M, x, y, q.d[by * b + bx]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sum[i] += q.d[by * b + bx][i];
+            su += 2.f * x / (float)f.Wo - 1.f;
+            sv += 2.f * y / (float)f.Ho - 1.f;
+        }
+    float md[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { md[i] = sum[i] / (float)BB; q.o[i] = tc[T_O + i]; }
+    q.u = su / (float)BB; q.v = sv / (float)BB;
+    float nrm = sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
+    float cosv = (md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2]) / nrm;
+    q.unit = ball_unit(tc[T_DISK], cosv);
+    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
+    float n0 = f.depth_range[((size_t)bi * 2) * hw + p], f0 = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
+    float vn = f.vol_range[((size_t)bi * 2) * hw + p], vf = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
+    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226
+    q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
+    q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
+}
+
+// One sample of a bundle: mid depth, normalised volume depth, sub-ray points, sphere radius.
+template <int BB>
+__device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB>& q, int k, float& z, float& dnorm,
+                                              float xyz[BB][3], float ctr[3], float& ball) {
+    float step = (q.farv - q.nearv) / (float)q.count;
+    float t0 = q.nearv + step * (float)k, t1 = q.nearv + step * (float)(k + 1);  // :183
+    z = 0.5f * (t0 + t1);                                                        // :246
+    dnorm = 2.f * (z - q.vnear) / (q.vfar - q.vnear) - 1.f;                      // :247
+    if (f.inv_depth) z = 1.f / z;                                                // :250-251
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < BB; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xyz[r][i] = q.o[i] + q.d[r][i] * z; s[i] += xyz[r][i]; }  // :255
+    float dd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ctr[i] = s[i] / (float)BB; float e = ctr[i] - q.o[i]; dd += e * e; }  // :256,:259
+    ball = sqrtf(dd) * q.unit;                                                   // :263
+}
+
+template <int BB>
+__global__ void k_counts(DevFrame f, int32_t* __restrict__ cnt) {
+    size_t nb = (size_t)f.B * f.H * f.W;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    int w = (int)(t % f.W); size_t r = t / f.W; int h = (int)(r % f.H); int bi = (int)(r / f.H);
+    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
+    float n0 = f.depth_range[((size_t)bi * 2) * hw + p], f0 = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
+    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
+    cnt[t] = sample_count(n0, f0, tar_cam(f, bi)[T_MINIV], f.S_max, f.adaptive);
+}
+
+// Exclusive scan of int32 counts: per-block scan, serial scan of the block sums, add-back.
+__global__ void k_scan_block(size_t n, const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t* __restrict__ bsum) {
+    __shared__ int32_t wsum[4];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    int32_t v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int32_t wo = 0;
+    for (int i = 0; i < wid; ++i) wo += wsum[i];
+    int32_t ex = wo + inc - s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == 255) bsum[blockIdx.x] = wo + inc;
+}
+
+__global__ void k_scan_sums(int nblk, int32_t* __restrict__ bsum) {  // one thread; nblk <= a few thousand
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t acc = 0;
+        for (int i = 0; i < nblk; ++i) { int32_t t = bsum[i]; bsum[i] = acc; acc += t; }
+        bsum[nblk] = acc;
+    }
+}
+
+__global__ void k_scan_add(size_t n, const int32_t* __restrict__ bsum, int32_t* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] += bsum[t / SCAN_BLOCK];
+}
+
+template <int BB>
+__global__ void k_sample(DevFrame f, const int32_t* __restrict__ offs, const int32_t* __restrict__ bsum, int nblk,
+                         float* __restrict__ rays_xyz, float* __restrict__ uvd, float* __restrict__ z_vals,
+                         float* __restrict__ ball_radii, int64_t* __restrict__ indices, int64_t* __restrict__ per_batch,
+                         int32_t* __restrict__ spb, int64_t* __restrict__ total) {
+    size_t nb = (size_t)f.B * f.H * f.W;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *total = bsum[nblk];
+    if (t >= nb) return;
+    int w = (int)(t % f.W); size_t r = t / f.W; int h = (int)(r % f.H); int bi = (int)(r / f.H);
+    Bundle<BB> q;
+    load_bundle<BB>(f, bi, h, w, q);
+    spb[t] = q.count;
+    int32_t off = offs[t];
+    size_t hw = (size_t)f.H * f.W;
+    if ((size_t)h * f.W + w == hw - 1) {  // last bundle of the batch item closes its sample range
+        per_batch[bi] = (int64_t)off + q.count;  // inclusive end; k_per_batch turns ends into counts
+    }
+    for (int k = 0; k < q.count; ++k) {
+        float z, dn, ball, xyz[BB][3], ctr[3];
+        bundle_sample<BB>(f, q, k, z, dn, xyz, ctr, ball);
+        size_t i = (size_t)off + k;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int s = 0; s < BB; ++s) rays_xyz[(i * 3 + c) * BB + s] = xyz[s][c];
+        uvd[i * 3 + 0] = q.u; uvd[i * 3 + 1] = q.v; uvd[i * 3 + 2] = dn;
+        z_vals[i] = z; ball_radii[i] = ball; indices[i] = (int64_t)t;
+    }
+}
+
+// per_batch holds inclusive end offsets after k_sample; turn them into per-batch counts.
+__global__ void k_per_batch(int B, int64_t* __restrict__ per_batch) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t prev = 0;
+        for (int i = 0; i < B; ++i) { int64_t e = per_batch[i]; per_batch[i] = e - prev; prev = e; }
+    }
+}
+
+template <int BB>
+static int sample_impl(const DevFrame& d, const WsLayout& L, void* ws, float* rays_xyz, float* uvd, float* z_vals,
+                       float* ball, int64_t* indices, int64_t* per_batch, int32_t* spb, int64_t* total, hipStream_t st) {
+    size_t nb = (size_t)d.B * d.H * d.W;
+    int32_t* cnt = (int32_t*)((char*)ws + L.cntOff);
+    int32_t* offs = (int32_t*)((char*)ws + L.offOff);
+    int32_t* bsum = (int32_t*)((char*)ws + L.bsumOff);
+    unsigned g = (unsigned)((nb + 255) / 256);
+    hipLaunchKernelGGL(k_counts<BB>, dim3(g), dim3(256), 0, st, d, cnt);
+    LAUNCH_CHECK("k_counts");
+    hipLaunchKernelGGL(k_scan_block, dim3(L.nBlocksScan), dim3(256), 0, st, nb, cnt, offs, bsum);
+    LAUNCH_CHECK("k_scan_block");
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, st, L.nBlocksScan, bsum);
+    LAUNCH_CHECK("k_scan_sums");
+    hipLaunchKernelGGL(k_scan_add, dim3(g), dim3(256), 0, st, nb, bsum, offs);
+    LAUNCH_CHECK("k_scan_add");
+    hipLaunchKernelGGL(k_sample<BB>, dim3(g), dim3(256), 0, st, d, offs, bsum, L.nBlocksScan, rays_xyz, uvd, z_vals, ball,
+                       indices, per_batch, spb, total);
+    LAUNCH_CHECK("k_sample");
+    hipLaunchKernelGGL(k_per_batch, dim3(1), dim3(64), 0, st, d.B, per_batch);
+    LAUNCH_CHECK("k_per_batch");
+    return GDB_OK;
+}
+
+extern "C" int gdb_sample(const GdbConfig* cfg, const GdbFrame* f, void* ws, float* rays_xyz, float* uvd, float* z_vals,
+                          float* ball, int64_t* indices, int64_t* per_batch, int32_t* spb, int64_t* total, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, true); if (rc) return rc;
+    if (!ws || !rays_xyz || !uvd || !z_vals || !ball || !indices || !per_batch || !spb || !total)
+        return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    WsLayout L = ws_layout(*cfg, *f);
+    DevFrame d = dev_frame(*cfg, *f, L, ws);
+    hipStream_t st = (hipStream_t)stream_;
+    switch (cfg->bundle_size) {
+        case 1: return sample_impl<1>(d, L, ws, rays_xyz, uvd, z_vals, ball, indices, per_batch, spb, total, st);
+        case 2: return sample_impl<4>(d, L, ws, rays_xyz, uvd, z_vals, ball, indices, per_batch, spb, total, st);
+        default: return sample_impl<16>(d, L, ws, rays_xyz, uvd, z_vals, ball, indices, per_batch, spb, total, st);
+    }
+}
+
+// ============================================================================================
+// A4  encode
+// ============================================================================================
+// Batch item of compacted sample i, from the per-batch counts (bundle_sampler.py:318-319,370).
+__device__ __forceinline__ int batch_of(int B, const int64_t* __restrict__ per_batch, int64_t i) {
+    int64_t acc = 0;
+    for (int bi = 0; bi < B; ++bi) { acc += per_batch[bi]; if (i < acc) return bi; }
+    return B - 1;
+}
+
+// Voxel feature: 5-D grid_sample, trilinear / border / align_corners=False.  :322-324
+// One thread per (sample, channel): consecutive samples sit on consecutive bundles, so the
+// NCDHW volume is read along x.
+__global__ void k_encode_vox(DevFrame f, const float* __restrict__ uvd, const int64_t* __restrict__ per_batch,
+                             const int64_t* __restrict__ total, float* __restrict__ vox) {
+    int64_t n = *total;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / GDB_CV; int c = (int)(t % GDB_CV);
+    if (i >= n) return;
+    int bi = batch_of(f.B, per_batch, i);
+    float x = gs_coord(uvd[i * 3 + 0], f.W), y = gs_coord(uvd[i * 3 + 1], f.H), z = gs_coord(uvd[i * 3 + 2], f.D);
+    float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+    float wx = x - xf, wy = y - yf, wz = z - zf;
+    int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+    const float* vol = f.feat_volume + ((size_t)bi * GDB_CV + c) * f.D * f.H * f.W;
+    float acc = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+                bool in = xx <= f.W - 1 && yy <= f.H - 1 && zz <= f.D - 1;
+                float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                float val = vol[((size_t)min(zz, f.D - 1) * f.H + min(yy, f.H - 1)) * f.W + min(xx, f.W - 1)];
+                acc += in ? val * wgt : 0.f;
+            }
+    vox[i * GDB_CV + c] = acc;
+}
+
+// Mip-mapped feature at texture coordinate (u,v) in [0,1]^2, level-of-detail `level`:
+// restatement of nvdiffrast.torch.texture(..., mip_level_bias=level, boundary_mode='clamp',
+// max_mip_level=L) as called at bundle_sampler.py:355-359.  Writes GDB_CFR floats.
+__device__ __forceinline__ void tex_level(const DevFrame& f, const float* __restrict__ pyr, int l, float u, float v,
+                                          float4 out[GDB_CP / 4]) {
+    int W = f.lvlW[l], H = f.lvlH[l];
+    int x0, x1, y0, y1; float fx, fy;
+    tex_coord(u, W, x0, x1, fx);
+    tex_coord(v, H, y0, y1, fy);
+    const float* base = pyr + f.lvlOff[l];
+    const float4* a00 = (const float4*)(base + ((size_t)y0 * W + x0) * GDB_CP);
+    const float4* a10 = (const float4*)(base + ((size_t)y0 * W + x1) * GDB_CP);
+    const float4* a01 = (const float4*)(base + ((size_t)y1 * W + x0) * GDB_CP);
+    const float4* a11 = (const float4*)(base + ((size_t)y1 * W + x1) * GDB_CP);
+#pragma unroll
+    for (int c = 0; c < GDB_CP / 4; ++c) {
+        float4 top = lerp4(a00[c], a10[c], fx);
+        float4 bot = lerp4(a01[c], a11[c], fx);
+        out[c] = lerp4(top, bot, fy);
+    }
+}
+
+__device__ __forceinline__ void tex_fetch(const DevFrame& f, const float* __restrict__ pyr, float u, float v, float level,
+                                          float4 out[GDB_CP / 4]) {
+    int l0, l1; float frac;
+    mip_select(level, f.levels, l0, l1, frac);
+    tex_level(f, pyr, l0, u, v, out);
+    if (frac > 0.f) {
+        float4 o1[GDB_CP / 4];
+        tex_level(f, pyr, l1, u, v, o1);
+#pragma unroll
+        for (int c = 0; c < GDB_CP / 4; ++c) out[c] = lerp4(out[c], o1[c], frac);
+    }
+}
+
+// Bilinear RGB at a projected point: 4-D grid_sample, border, align_corners=False.  :336
+__device__ __forceinline__ void rgb_fetch(const float* __restrict__ img, int Ho, int Wo, float gx, float gy, float rgb[3]) {
+    float x = gs_coord(gx, Wo), y = gs_coord(gy, Ho);
+    float xf = floorf(x), yf = floorf(y);
+    float wx = x - xf, wy = y - yf, ex = 1.f - wx, ey = 1.f - wy;
+    int x0 = (int)xf, y0 = (int)yf;
+    bool inx = x0 + 1 <= Wo - 1, iny = y0 + 1 <= Ho - 1;
+    int x1 = min(x0 + 1, Wo - 1), y1 = min(y0 + 1, Ho - 1);
+    float w00 = ex * ey, w10 = inx ? wx * ey : 0.f, w01 = iny ? ex * wy : 0.f, w11 = (inx && iny) ? wx * wy : 0.f;
+    size_t plane = (size_t)Ho * Wo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = img + c * plane;
+        rgb[c] = p[(size_t)y0 * Wo + x0] * w00 + p[(size_t)y0 * Wo + x1] * w10 + p[(size_t)y1 * Wo + x0] * w01 +
+                 p[(size_t)y1 * Wo + x1] * w11;
+    }
+}
+
+__device__ __forceinline__ void normalize3(const float a[3], float o[3]) {  // F.normalize, eps 1e-12
+    float n = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
+    o[0] = a[0] / n; o[1] = a[1] / n; o[2] = a[2] / n;
+}
+
+// One (view, sample): per-sub-ray RGB, mip-mapped feature, view-direction code.  :327-369
+template <int BB>
+__global__ void k_encode_views(DevFrame f, const float* __restrict__ rays_xyz, const float* __restrict__ ball_radii,
+                               const int64_t* __restrict__ per_batch, const int64_t* __restrict__ total, int64_t n_alloc,
+                               float* __restrict__ out) {
+    constexpr int P = 3 * BB + GDB_CFR + 4;
+    int64_t n = *total;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = blockIdx.y;
+    if (i >= n) return;
+    int bi = batch_of(f.B, per_batch, i);
+    const float* sc = src_cam(f, bi, v);
+    const float* tc = tar_cam(f, bi);
+    float* o = out + ((size_t)v * n_alloc + i) * P;
+    const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
+
+    float cw[3] = {0.f, 0.f, 0.f}, cc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < BB; ++s) {
+        float p[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c] = rays_xyz[((size_t)i * 3 + c) * BB + s]; cw[c] += p[c]; }
+        float cam[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            cam[r] = sc[S_E + 4 * r] * p[0] + sc[S_E + 4 * r + 1] * p[1] + sc[S_E + 4 * r + 2] * p[2] + sc[S_E + 4 * r + 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cc[c] += cam[c];
+        float im[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cam[0] + sc[S_K + 3 * r + 1] * cam[1] + sc[S_K + 3 * r + 2] * cam[2];
+        float zc = fmaxf(im[2], 1e-6f);
+        float gx = 2.f * (im[0] / zc) / (float)f.Wo - 1.f, gy = 2.f * (im[1] / zc) / (float)f.Ho - 1.f;
+        float rgb[3];
+        rgb_fetch(img, f.Ho, f.Wo, gx, gy, rgb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c * BB + s] = rgb[c];  // channel order c*b²+sub  :337
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { cw[c] = cw[c] / (float)BB; cc[c] = cc[c] / (float)BB; }
+
+    float level = mip_level(cc[0], cc[1], cc[2], ball_radii[i], sc[S_PIXR]);
+    float ci[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ci[r] = sc[S_KS + 3 * r] * cc[0] + sc[S_KS + 3 * r + 1] * cc[1] + sc[S_KS + 3 * r + 2] * cc[2];
+    float zc = fmaxf(ci[2], 1e-6f);
+    float tu = ci[0] / zc / (float)f.W, tv = ci[1] / zc / (float)f.H;
+    float4 ft[GDB_CP / 4];
+    tex_fetch(f, f.pyr + ((size_t)bi * f.V + v) * f.pyrStride, tu, tv, level, ft);
+    const float* ff = (const float*)ft;
+#pragma unroll
+    for (int c = 0; c < GDB_CFR; ++c) o[3 * BB + c] = ff[c];
+
+    float td[3], sd[3], a[3], dif[3], dn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = cw[c] - tc[T_O + c];
+    normalize3(a, td);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = cw[c] - sc[S_C + c];
+    normalize3(a, sd);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dif[c] = td[c] - sd[c];
+    normalize3(dif, dn);
+    o[3 * BB + GDB_CFR + 0] = dn[0]; o[3 * BB + GDB_CFR + 1] = dn[1]; o[3 * BB + GDB_CFR + 2] = dn[2];
+    o[3 * BB + GDB_CFR + 3] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2];
+}
+
+extern "C" int gdb_encode(const GdbConfig* cfg, const GdbFrame* f, const void* ws, const float* rays_xyz, const float* uvd,
+                          const float* ball, const int64_t* per_batch, const int64_t* total, int64_t n_alloc, float* out,
+                          float* vox, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, true); if (rc) return rc;
+    if (!ws || !rays_xyz || !uvd || !ball || !per_batch || !total || !out || !vox) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (n_alloc < 1 || n_alloc > (int64_t)f->B * f->H * f->W * cfg->max_num_samples)
+        return gdb_fail(GDB_E_SHAPE, "n_alloc %lld outside 1..B*H*W*S_max", (long long)n_alloc);
+    WsLayout L = ws_layout(*cfg, *f);
+    DevFrame d = dev_frame(*cfg, *f, L, ws);
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_encode_vox, dim3((unsigned)((n_alloc * GDB_CV + 255) / 256)), dim3(256), 0, st, d, uvd, per_batch, total, vox);
+    LAUNCH_CHECK("k_encode_vox");
+    dim3 g((unsigned)((n_alloc + 127) / 128), f->V);
+    switch (cfg->bundle_size) {
+        case 1: hipLaunchKernelGGL(k_encode_views<1>, g, dim3(128), 0, st, d, rays_xyz, ball, per_batch, total, n_alloc, out); break;
+        case 2: hipLaunchKernelGGL(k_encode_views<4>, g, dim3(128), 0, st, d, rays_xyz, ball, per_batch, total, n_alloc, out); break;
+        default: hipLaunchKernelGGL(k_encode_views<16>, g, dim3(128), 0, st, d, rays_xyz, ball, per_batch, total, n_alloc, out); break;
+    }
+    LAUNCH_CHECK("k_encode_views");
+    return GDB_OK;
+}

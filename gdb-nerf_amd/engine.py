@@ -1,0 +1,247 @@
+"""Torch-facing driver of the HIP hot path.  PyTorch is plumbing here (device memory, the
+current stream); all arithmetic happens in libgdbnerf_hip.so through the C ABI.
+
+A frame is a dict of contiguous float32 CUDA tensors with the reference's layouts
+(Network.forward, network.py:114-166 of the reference):
+    src_images (B,V,3,Ho,Wo)   img_feat (B,V,C_f+3,H,W)   feat_volume (B,C_v,D,H,W)
+    depth_range, vol_range (B,2,H,W)   src_exts (B,V,4,4)   src_ints (B,V,3,3)
+    tar_ext (B,4,4)   tar_int (B,3,3)   near_far (B,2)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GdbConfig, GdbFrame
+
+NERF_KEYS = ("view_fc.0", "global_fc.0", "agg_w_fc.0", "fc.0", "lr0.0", "sigma.0", "weight.0", "weight.2", "feat_head.0")
+
+_FRAME_SHAPES = {
+    "src_images": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, V, 3, Ho, Wo),
+    "img_feat": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, V, Cf + 3, H, W),
+    "feat_volume": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, Cv, D, H, W),
+    "depth_range": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, 2, H, W),
+    "vol_range": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, 2, H, W),
+    "src_exts": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, V, 4, 4),
+    "src_ints": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, V, 3, 3),
+    "tar_ext": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, 4, 4),
+    "tar_int": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, 3, 3),
+    "near_far": lambda B, V, Ho, Wo, H, W, D, Cf, Cv: (B, 2),
+}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+class HotPathEngine:
+    """One engine per (config, device).  Not thread-safe: one frame in flight per engine."""
+
+    def __init__(self, *, bundle_size: int = 2, max_num_samples: int = 3, is_adaptive: bool = True,
+                 inv_depth: bool = False, global_num_depth: int = 64, max_mipmap_level: int = 3,
+                 feat_dim: int = 16, voxel_dim: int = 8, hid_dim: int = 64, viewdir_agg: bool = True,
+                 device: str | torch.device = "cuda"):
+        self.lib = _lib.load()
+        self.cfg = GdbConfig(int(bundle_size), int(max_num_samples), int(bool(is_adaptive)), int(bool(inv_depth)),
+                             int(global_num_depth), int(max_mipmap_level), int(feat_dim), int(voxel_dim),
+                             int(hid_dim), int(bool(viewdir_agg)))
+        n = C.c_size_t()
+        _lib.check(self.lib.gdb_packed_weight_floats(C.byref(self.cfg), C.byref(n)))  # validates the config
+        self._n_packed = n.value
+        self.device = torch.device(device)
+        self.weights: Optional[torch.Tensor] = None
+        self._frame: Optional[GdbFrame] = None
+        self._keep: Dict[str, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- derived sizes -------------------------------------------------------------------
+    @property
+    def b(self) -> int:
+        return self.cfg.bundle_size
+
+    @property
+    def P(self) -> int:  # per-view channels [rgbs | feat | rgb | dir]
+        return 3 * self.b * self.b + self.cfg.feat_dim + 3 + 4
+
+    @property
+    def Q(self) -> int:  # per-bundle output channels
+        return 3 * self.b * self.b + self.cfg.feat_dim + 3 + self.cfg.voxel_dim
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- weights -------------------------------------------------------------------------
+    def load_weights(self, state: Dict[str, "torch.Tensor | np.ndarray"], prefix: str = "") -> None:
+        """Pack the 18 NeRF tensors (keys `<prefix>view_fc.0.weight` ...) and upload them once."""
+        arrs, ptrs = [], (C.c_void_p * 18)()
+        for i, key in enumerate(NERF_KEYS):
+            for j, suffix in enumerate((".weight", ".bias")):
+                k = prefix + key + suffix
+                if k not in state:
+                    if key == "view_fc.0" and not self.cfg.viewdir_agg:
+                        ptrs[2 * i + j] = None
+                        continue
+                    raise KeyError(k)
+                v = state[k]
+                a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+                arrs.append(a)
+                ptrs[2 * i + j] = a.ctypes.data
+        expect = {"view_fc.0": (19, 4), "global_fc.0": (32, 57), "agg_w_fc.0": (1, 32), "fc.0": (16, 32), "lr0.0": (64, 24),
+                  "sigma.0": (1, 64), "weight.0": (64, 111), "weight.2": (1, 64), "feat_head.0": (8, 64)}
+        for key, shp in expect.items():
+            k = prefix + key + ".weight"
+            if k in state and tuple(state[k].shape) != shp:
+                raise ValueError(f"{k} has shape {tuple(state[k].shape)}, expected {shp}")
+        host = np.zeros(self._n_packed, dtype=np.float32)
+        _lib.check(self.lib.gdb_pack_weights(C.byref(self.cfg), ptrs, host.ctypes.data))
+        self.weights = torch.from_numpy(host).to(self.device)
+
+    # ---- per-frame preparation -----------------------------------------------------------
+    def prepare(self, frame: Dict[str, torch.Tensor]) -> None:
+        """Validate shapes on the host, then build the camera block and the feature pyramid."""
+        si = frame["src_images"]
+        if si.dim() != 5:
+            raise ValueError("src_images must be (B,V,3,Ho,Wo)")
+        B, V, _, Ho, Wo = si.shape
+        b = self.b
+        if Ho % b or Wo % b:
+            raise ValueError(f"image {Ho}x{Wo} not divisible by bundle_size {b}")
+        H, W = Ho // b, Wo // b
+        D = frame["feat_volume"].shape[2]
+        dims = (B, V, Ho, Wo, H, W, D, self.cfg.feat_dim, self.cfg.voxel_dim)
+        for name, shp in _FRAME_SHAPES.items():
+            _chk(frame[name], name, shp(*dims))
+        f = GdbFrame(B, V, Ho, Wo, H, W, D, *(frame[k].data_ptr() for k in (
+            "src_images", "img_feat", "feat_volume", "depth_range", "vol_range", "src_exts", "src_ints",
+            "tar_ext", "tar_int", "near_far")))
+        need = C.c_size_t()
+        _lib.check(self.lib.gdb_workspace_bytes(C.byref(self.cfg), C.byref(f), C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        self._frame, self._keep = f, dict(frame)
+        _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+
+    def _need_frame(self) -> GdbFrame:
+        if self._frame is None:
+            # bundle_sampler.py:220-221 of the reference
+            raise ValueError("Rays have not been built yet. Please call prepare() first.")
+        return self._frame
+
+    @property
+    def n_bundles(self) -> int:
+        f = self._need_frame()
+        return f.B * f.H * f.W
+
+    # ---- operator mirrors ----------------------------------------------------------------
+    def build_rays(self) -> Dict[str, torch.Tensor]:
+        f = self._need_frame()
+        dev = self.device
+        out = {"rays_d": torch.empty((f.B, f.Ho, f.Wo, 3), device=dev), "uv": torch.empty((f.Ho, f.Wo, 2), device=dev),
+               "rays_o": torch.empty((f.B, 3), device=dev), "z_axis": torch.empty((f.B, 3), device=dev),
+               "tar_pixel_radius": torch.empty((f.B,), device=dev)}
+        _lib.check(self.lib.gdb_build_rays(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), *(out[k].data_ptr() for k in (
+            "rays_d", "uv", "rays_o", "z_axis", "tar_pixel_radius")), self._stream()))
+        return out
+
+    def sample(self) -> Dict[str, torch.Tensor]:
+        """Arrays are allocated for N_max = n_bundles * S_max; `total` (device int64) holds the valid count."""
+        f = self._need_frame()
+        dev, bb = self.device, self.b * self.b
+        nmax = self.n_bundles * self.cfg.max_num_samples
+        out = {"rays_xyz": torch.empty((nmax, 3, bb), device=dev), "uvd": torch.empty((nmax, 3), device=dev),
+               "z_vals": torch.empty((nmax,), device=dev), "ball_radii": torch.empty((nmax,), device=dev),
+               "indices": torch.empty((nmax,), dtype=torch.int64, device=dev),
+               "samples_per_batch": torch.empty((f.B,), dtype=torch.int64, device=dev),
+               "samples_per_bundle": torch.empty((self.n_bundles,), dtype=torch.int32, device=dev),
+               "total": torch.empty((1,), dtype=torch.int64, device=dev)}
+        _lib.check(self.lib.gdb_sample(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), *(out[k].data_ptr() for k in (
+            "rays_xyz", "uvd", "z_vals", "ball_radii", "indices", "samples_per_batch", "samples_per_bundle", "total")),
+            self._stream()))
+        return out
+
+    def encode(self, rays_xyz: torch.Tensor, uvd: torch.Tensor, ball_radii: torch.Tensor,
+               samples_per_batch: torch.Tensor, total: torch.Tensor):
+        f = self._need_frame()
+        n = rays_xyz.shape[0]
+        bb = self.b * self.b
+        _chk(rays_xyz, "rays_xyz", (n, 3, bb)); _chk(uvd, "uvd", (n, 3)); _chk(ball_radii, "ball_radii", (n,))
+        _chk(samples_per_batch, "samples_per_batch", (f.B,), torch.int64); _chk(total, "total", (1,), torch.int64)
+        rfd = torch.empty((f.V, n, self.P), device=self.device)
+        vox = torch.empty((n, self.cfg.voxel_dim), device=self.device)
+        _lib.check(self.lib.gdb_encode(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), rays_xyz.data_ptr(), uvd.data_ptr(),
+                                       ball_radii.data_ptr(), samples_per_batch.data_ptr(), total.data_ptr(), n,
+                                       rfd.data_ptr(), vox.data_ptr(), self._stream()))
+        return rfd, vox
+
+    def mlp(self, vox_feat: torch.Tensor, rgbs_feat_dir: torch.Tensor, total: Optional[torch.Tensor] = None):
+        if self.weights is None:
+            raise ValueError("load_weights() first")
+        V, n, P = rgbs_feat_dir.shape
+        _chk(rgbs_feat_dir, "rgbs_feat_dir", (V, n, self.P)); _chk(vox_feat, "vox_feat", (n, self.cfg.voxel_dim))
+        if total is not None:
+            _chk(total, "total", (1,), torch.int64)
+        sigma = torch.empty((n,), device=self.device)
+        feat = torch.empty((n, self.Q), device=self.device)
+        _lib.check(self.lib.gdb_mlp(C.byref(self.cfg), self.weights.data_ptr(), V, vox_feat.data_ptr(), rgbs_feat_dir.data_ptr(),
+                                    _ptr(total), n, sigma.data_ptr(), feat.data_ptr(), self._stream()))
+        return sigma, feat
+
+    def composite(self, sigma: torch.Tensor, feat: torch.Tensor, z_vals: torch.Tensor, indices: torch.Tensor,
+                  n_bundles: int, total: Optional[torch.Tensor] = None):
+        n, ch = feat.shape
+        _chk(sigma, "sigma", (n,)); _chk(feat, "feat", (n, ch)); _chk(z_vals, "z_vals", (n,))
+        _chk(indices, "indices", (n,), torch.int64)
+        if total is not None:
+            _chk(total, "total", (1,), torch.int64)
+        dev = self.device
+        weights = torch.zeros((n,), device=dev)
+        bf = torch.empty((n_bundles, ch), device=dev)
+        depth = torch.empty((n_bundles,), device=dev)
+        opac = torch.empty((n_bundles,), device=dev)
+        scratch = torch.empty((2 * n_bundles,), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.gdb_composite(C.byref(self.cfg), sigma.data_ptr(), feat.data_ptr(), z_vals.data_ptr(),
+                                          indices.data_ptr(), _ptr(total), n, n_bundles, ch, weights.data_ptr(), bf.data_ptr(),
+                                          depth.data_ptr(), opac.data_ptr(), scratch.data_ptr(), self._stream()))
+        return weights, bf, depth, opac
+
+    def render_unfused(self):
+        """build_rays → sample → encode → MLP → composite through the operator mirrors (all fp32)."""
+        s = self.sample()
+        rfd, vox = self.encode(s["rays_xyz"], s["uvd"], s["ball_radii"], s["samples_per_batch"], s["total"])
+        sigma, feat = self.mlp(vox, rfd, s["total"])
+        _, bf, depth, opac = self.composite(sigma, feat, s["z_vals"], s["indices"], self.n_bundles, s["total"])
+        return bf, depth, opac
+
+    # ---- production entry ----------------------------------------------------------------
+    def render(self, row_begin: int = 0, row_end: Optional[int] = None, precision: int = 0, out=None):
+        """Fused hot path over bundle-map rows [row_begin,row_end) of every batch item."""
+        if self.weights is None:
+            raise ValueError("load_weights() first")
+        f = self._need_frame()
+        row_end = f.H if row_end is None else row_end
+        nb = self.n_bundles
+        if out is None:
+            out = (torch.zeros((nb, self.Q), device=self.device), torch.zeros((nb,), device=self.device),
+                   torch.zeros((nb,), device=self.device))
+        bf, depth, opac = out
+        _chk(bf, "bundle_feat", (nb, self.Q)); _chk(depth, "depth", (nb,)); _chk(opac, "opacity", (nb,))
+        _lib.check(self.lib.gdb_render_bundles_fused(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
+                                                     int(row_begin), int(row_end), int(precision), bf.data_ptr(), depth.data_ptr(),
+                                                     opac.data_ptr(), self._stream()))
+        return bf, depth, opac

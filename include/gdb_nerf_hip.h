@@ -1,0 +1,165 @@
+/*
+ * gdb_nerf_hip.h — C ABI of libgdbnerf_hip.so: the GDB-NeRF depth-guided bundle-sampling hot
+ * path as HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (KLMAV-CUC/GDB-NeRF) is pure Python; it has no FFI of its own.  Each entry
+ * point below replaces one Python operator of the reference (file:line relative to the
+ * reference root) or one of the two third-party CUDA ops that operator calls.  The
+ * reference-side binding a maintainer would add is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.
+ *  - Every pointer named d_* is DEVICE memory owned by the caller; the library never
+ *    allocates, frees or retains device memory.  h_* pointers are host memory.
+ *  - All tensors are contiguous float32 in the reference's own layouts unless stated.
+ *  - Every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); nothing
+ *    synchronises with the host.  Data-dependent sample counts stay on the device.
+ *  - Return value: GDB_OK (0) or a negative GdbStatus; gdb_last_error() returns a
+ *    thread-local message for the last failure on the calling thread.  Shape / config
+ *    violations are rejected before any launch.  Kernels are NaN-transparent like the
+ *    reference.
+ */
+#ifndef GDB_NERF_HIP_H
+#define GDB_NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDB_ABI_VERSION 1
+
+typedef enum GdbStatus {
+    GDB_OK = 0,
+    GDB_E_BADARG = -1,   /* null pointer, non-positive size, unsupported option */
+    GDB_E_SHAPE = -2,    /* sizes inconsistent with each other or with the config */
+    GDB_E_HIP = -3,      /* a HIP runtime call failed (message carries hipGetErrorString) */
+    GDB_E_WORKSPACE = -4 /* workspace too small */
+} GdbStatus;
+
+/* Knobs of the path; names follow the reference's YAML keys (configs/dtu_pretrain.yaml:17-42,
+ * read at networks/gdb_nerf/network.py:29-47). */
+typedef struct GdbConfig {
+    int32_t bundle_size;      /* nerf.bundle_size: b, power of two, 1..4 */
+    int32_t max_num_samples;  /* nerf.max_num_samples: S_max, 1..GDB_MAX_SAMPLES */
+    int32_t is_adaptive;      /* nerf.is_adaptive */
+    int32_t inv_depth;        /* mvs.inv_depth[-1] */
+    int32_t global_num_depth; /* nerf.global_num_depth */
+    int32_t max_mipmap_level; /* nerf.max_mipmap_level, 0..GDB_MAX_MIP */
+    int32_t feat_dim;         /* fpn.feat_dims[feat_level]: C_f (img_feat carries C_f+3 channels) */
+    int32_t voxel_dim;        /* mvs.voxel_dim: C_v */
+    int32_t hid_dim;          /* nerf.nerf_hidden_dims */
+    int32_t viewdir_agg;      /* nerf.viewdir_agg */
+} GdbConfig;
+
+#define GDB_MAX_SAMPLES 16
+#define GDB_MAX_MIP 4
+#define GDB_MAX_VIEWS 8
+
+/* One batch of hot-path inputs (Network.forward, network.py:114-166). */
+typedef struct GdbFrame {
+    int32_t B, V;             /* batch, source views */
+    int32_t Ho, Wo;           /* target / source image size */
+    int32_t H, W;             /* bundle map size: Ho/b, Wo/b */
+    int32_t D;                /* depth planes of feat_volume */
+    const float* d_src_images;  /* (B,V,3,Ho,Wo) */
+    const float* d_img_feat;    /* (B,V,C_f+3,H,W): FPN level ⊕ downsampled RGB, network.py:159-164 */
+    const float* d_feat_volume; /* (B,C_v,D,H,W) */
+    const float* d_depth_range; /* (B,2,H,W) near/far of the depth prior */
+    const float* d_vol_range;   /* (B,2,H,W) near/far of the cost volume */
+    const float* d_src_exts;    /* (B,V,4,4) world-to-camera */
+    const float* d_src_ints;    /* (B,V,3,3) */
+    const float* d_tar_exts;    /* (B,4,4) world-to-camera */
+    const float* d_tar_ints;    /* (B,3,3) */
+    const float* d_near_far;    /* (B,2) scene near/far */
+} GdbFrame;
+
+/* ---- library ------------------------------------------------------------------------ */
+int gdb_abi_version(void);
+const char* gdb_last_error(void);
+
+/* Bytes of device workspace gdb_prepare() needs for a frame of this shape (camera block,
+ * channel-last feature pyramid, per-bundle counts/offsets). */
+int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes);
+
+/* ---- MLP weights -------------------------------------------------------------------- */
+/* Number of floats in the packed weight buffer for cfg (fp32 section + MFMA-fragment
+ * section). */
+int gdb_packed_weight_floats(const GdbConfig* cfg, size_t* out_floats);
+/* Pack the 18 NeRF tensors (state-dict order of networks/gdb_nerf/nerf.py:20-56:
+ * view_fc.0, global_fc.0, agg_w_fc.0, fc.0, lr0.0, sigma.0, weight.0, weight.2,
+ * feat_head.0; each .weight (out,in) row-major then .bias) into h_out.  Host only; the
+ * caller uploads h_out to the device once per checkpoint.  If viewdir_agg is 0 the first
+ * two pointers may be NULL. */
+int gdb_pack_weights(const GdbConfig* cfg, const float* const h_tensors[18], float* h_out);
+
+/* ---- per-frame preparation ---------------------------------------------------------- */
+/* Camera block (matrix inverses, ray matrix, pixel radii: bundle_sampler.py:67-74,304-313)
+ * and the channel-last mip pyramid of img_feat (what nvdiffrast.texture builds on every
+ * call, bundle_sampler.py:355-359).  The workspace also reserves room for the per-bundle
+ * sample counts and their exclusive scan, which gdb_sample fills
+ * (bundle_sampler.py:179,182-189). */
+int gdb_prepare(const GdbConfig* cfg, const GdbFrame* frame, void* d_workspace, size_t workspace_bytes,
+                void* stream);
+
+/* ---- operator mirrors (one per reference method) ------------------------------------ */
+/* BundleSampler.build_rays, bundle_sampler.py:30-74.  Needs gdb_prepare on the same
+ * workspace first.  Outputs: d_rays_d (B,Ho,Wo,3), d_uv (Ho,Wo,2), d_rays_o (B,3),
+ * d_z_axis (B,3), d_tar_pixel_radius (B). */
+int gdb_build_rays(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace, float* d_rays_d,
+                   float* d_uv, float* d_rays_o, float* d_z_axis, float* d_tar_pixel_radius, void* stream);
+
+/* BundleSampler.sample, bundle_sampler.py:193-265.  Needs gdb_prepare first.  Arrays are
+ * sized for the maximum N_max = B*H*W*S_max; the first *d_total entries are valid, in the
+ * reference's order (bundle-major, sample-minor).  d_rays_xyz (N_max,3,b*b), d_uvd (N_max,3),
+ * d_z_vals, d_ball_radii (N_max), d_indices int64 (N_max), d_samples_per_batch int64 (B),
+ * d_samples_per_bundle int32 (B*H*W), d_total int64 (1). */
+int gdb_sample(const GdbConfig* cfg, const GdbFrame* frame, void* d_workspace, float* d_rays_xyz,
+               float* d_uvd, float* d_z_vals, float* d_ball_radii, int64_t* d_indices,
+               int64_t* d_samples_per_batch, int32_t* d_samples_per_bundle, int64_t* d_total, void* stream);
+
+/* BundleSampler.encode, bundle_sampler.py:267-371 (including the nvdiffrast.torch.texture
+ * call at :355-359 and the two F.grid_sample calls at :323,:336).  Needs gdb_prepare first.
+ * n_alloc = rows allocated in the sample arrays / outputs; the valid count is read on the
+ * device from d_total and d_samples_per_batch.  Outputs d_rgbs_feat_dir (V,n_alloc,3b²+C_f+3+4),
+ * d_vox_feat (n_alloc,C_v). */
+int gdb_encode(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace, const float* d_rays_xyz,
+               const float* d_uvd, const float* d_ball_radii, const int64_t* d_samples_per_batch,
+               const int64_t* d_total, int64_t n_alloc, float* d_rgbs_feat_dir, float* d_vox_feat,
+               void* stream);
+
+/* NeRF.forward, networks/gdb_nerf/nerf.py:84-115, exact fp32.  d_rgbs_feat_dir (V,n_alloc,P)
+ * with P = 3b²+C_f+3+4; rows [0,n) are processed (n from *d_total when d_total != NULL, else
+ * n_alloc).  Outputs d_sigma (n_alloc), d_feat (n_alloc, P-4+C_v). */
+int gdb_mlp(const GdbConfig* cfg, const float* d_packed_weights, int32_t V, const float* d_vox_feat,
+            const float* d_rgbs_feat_dir, const int64_t* d_total, int64_t n_alloc, float* d_sigma,
+            float* d_feat, void* stream);
+
+/* render_weight_from_density + accumulate_value_along_rays, networks/gdb_nerf/utils.py:19-43,
+ * 88-121 (nerfacc.volrend.render_weight_from_alpha / accumulate_along_rays at :35,:110), with
+ * the inv_depth handling of Network.render_bundles, network.py:83-89.  d_indices sorted
+ * ascending.  channels = columns of d_feat.  Outputs d_weights (n_alloc), d_bundle_feat
+ * (n_bundles,channels), d_depth, d_opacity (n_bundles). */
+int gdb_composite(const GdbConfig* cfg, const float* d_sigma, const float* d_feat, const float* d_z_vals,
+                  const int64_t* d_indices, const int64_t* d_total, int64_t n_alloc, int64_t n_bundles,
+                  int32_t channels, float* d_weights, float* d_bundle_feat, float* d_depth, float* d_opacity,
+                  void* d_scratch_2xnbundles_i32, void* stream);
+
+/* ---- production entry ---------------------------------------------------------------- */
+/* The whole hot-path section of Network.forward (network.py:145-169: build_rays → sample →
+ * encode → render_bundles) in one pass with no intermediate in HBM.  Needs gdb_prepare on
+ * the same workspace first.  row_begin/row_end select a strip of bundle-map rows
+ * [row_begin,row_end) of every batch item (multi-GPU row-strip sharding); outputs are full
+ * size and only the strip's rows are written.  precision: 0 = fp16 MFMA, fp32 accumulate.
+ * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
+int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
+                             const float* d_packed_weights, int32_t row_begin, int32_t row_end,
+                             int32_t precision, float* d_bundle_feat, float* d_depth, float* d_opacity,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDB_NERF_HIP_H */
