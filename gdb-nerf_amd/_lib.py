@@ -60,6 +60,10 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise GdbError(f"{LIB_PATH} not found: the HIP hot path is not built "
                            "(run `python gdb-nerf_amd/build.py`); there is no CPU fallback")
+        # torch bundles its own HIP runtime (SONAME-compatible with the one hipcc links against).
+        # It must be in the process first so that this library binds to the SAME runtime as the
+        # tensors and streams it is handed; loading in the other order maps two runtimes.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -1,9 +1,613 @@
-// placeholder until the fused kernel lands
+// Production kernel: the whole hot-path section of Network.forward (network.py:145-169 of the
+// reference: build_rays → sample → encode → NeRF MLP → normalised alpha composite) in ONE
+// launch, with no per-sample intermediate in HBM.
+//
+// Mapping (gfx950, wave64):
+//   workgroup  = one 32-bundle segment of a bundle-map row; wave w handles sample slots
+//                k = w, w+nw, ... of those bundles (one slot per wave when S_max fits).
+//   lane       = (j = lane&31: bundle of the segment, h = lane>>5: "half").  The two halves
+//                of a wave split every per-sample vector exactly the way the 32x32 MFMA
+//                accumulator splits its rows: half h owns rows 4h..4h+3 of every 8.
+//   gather     = coalesced along the row: the NCDHW cost volume and the NCHW images are read
+//                along x by consecutive lanes; feature texels (20 floats, channel-last
+//                pyramid) are read as 16-B chunks, chunk parity = h.
+//   MLP        = every layer is D = W · Xᵀ on v_mfma_f32_32x32x16_f16 (samples on the MFMA
+//                column = lane, features on the accumulator rows).  A layer's accumulator is
+//                converted in place to the next layer's B operand (weights are pre-permuted
+//                on the host to the accumulator's row order), so activations never leave
+//                registers; views are separate accumulators of the same 32 samples, which
+//                makes variance/mean/softmax over views per-lane arithmetic.
+//   composite  = per-slot results meet in LDS; transmittance weights, normalisation and the
+//                weighted sum run per bundle; the (N_b, 39) output rows are written as one
+//                contiguous run per segment.
 #include "gdb_internal.h"
+#include <cstring>
+#include <vector>
+
 int gdb_fail(int code, const char* fmt, ...);
-size_t gdb_mfma_section_floats() { return 0; }
-void gdb_pack_mfma_section(const float*, float*) {}
-extern "C" int gdb_render_bundles_fused(const GdbConfig*, const GdbFrame*, const void*, const float*, int32_t, int32_t,
-                                        int32_t, float*, float*, float*, void*) {
-    return gdb_fail(GDB_E_BADARG, "fused kernel not built yet");
+int gdb_check_cfg(const GdbConfig* c);
+int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs);
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- MFMA section of the packed weights ---------------------------------------------------------
+// 33 A-operand fragments (64 lanes x 8 halfs = 256 floats each), then fp32 tables.
+enum {
+    F_VIEW = 0,   // view_fc, k-step 1 of the tail vector (dir)
+    F_GVAR = 1,   // global_fc columns [19,38) on var, k-steps 0,1
+    F_GMEAN = 3,  // global_fc columns [38,57) on mean
+    F_GA = 5,     // global_fc columns [0,19) on g_v
+    F_FC = 7,     // fc on the aggregated 32-vector
+    F_LR0 = 9,    // lr0: [out tile][k-step: 0 = im, 1 = vox]
+    F_FH = 13,    // rows 0..7 feat_head, row 8 sigma, on x: [x tile][k-step]
+    F_W0A = 17,   // weight.0 columns [0,64) on x: [out tile][x tile][k-step]
+    F_W0B = 25,   // weight.0 columns [64,88) on [vox|im]: [out tile][k-step]
+    F_W0C = 29,   // weight.0 columns [88,111) on the per-view tail: [out tile][k-step]
+    N_FRAGS = 33
+};
+enum {
+    TB_VIEW = N_FRAGS * 256,  // biases in accumulator layout [h][16]
+    TB_GLOB = TB_VIEW + 32,
+    TB_FC = TB_GLOB + 32,
+    TB_LR0 = TB_FC + 32,      // [out tile][h][16]
+    TB_FH = TB_LR0 + 64,
+    TB_W0 = TB_FH + 32,       // [out tile][h][16]
+    TD_AGG = TB_W0 + 64,      // agg_w_fc weights in accumulator layout
+    TD_W2 = TD_AGG + 32,      // weight.2 weights [tile][h][16]
+    TS_BAGG = TD_W2 + 64,
+    TS_BW2 = TS_BAGG + 1,
+    MFMA_FLOATS = (TS_BW2 + 1 + 63) / 64 * 64
+};
+
+size_t gdb_mfma_section_floats() { return MFMA_FLOATS; }
+
+// Accumulator row of (register r, half h) in a 32x32 MFMA tile; also the k index that element
+// (r & 7) of k-step (r >> 3) carries when the tile is reused as a B operand.
+static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+namespace {
+struct Packer {
+    const float* w;  // fp32 section
+    float* out;      // MFMA section
+    // kmap(h, i) -> column of W (or -1 for a zero), rows r -> output feature rowmap(r) (or -1)
+    template <class RowMap, class KMap>
+    void frag(int idx, int wOff, int ld, RowMap rowmap, KMap kmap) {
+        _Float16* f = (_Float16*)(out + (size_t)idx * 256);
+        for (int l = 0; l < 64; ++l) {
+            int r = l & 31, h = l >> 5, orow = rowmap(r);
+            for (int i = 0; i < 8; ++i) {
+                int col = kmap(h, i);
+                float v = (orow >= 0 && col >= 0) ? w[wOff + orow * ld + col] : 0.f;
+                f[l * 8 + i] = (_Float16)v;
+            }
+        }
+    }
+    template <class RowMap>
+    void table(int off, int srcOff, int stride, RowMap rowmap) {
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                int o = rowmap(acc_row(r, h));
+                out[off + h * 16 + r] = o >= 0 ? w[srcOff + o * stride] : 0.f;
+            }
+    }
+};
+}  // namespace
+
+void gdb_pack_mfma_section(const float* fp32, float* out) {
+    Packer p{fp32, out};
+    memset(out, 0, sizeof(float) * MFMA_FLOATS);
+    auto vrow = [](int s, int h, int i) { return 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); };
+    auto lt = [](int n) { return [n](int r) { return r < n ? r : -1; }; };
+    auto tile = [](int t, int n) { return [t, n](int r) { return 32 * t + r < n ? 32 * t + r : -1; }; };
+    // tail vector tv[32]: [0,19) feat ⊕ rgb, [24,28) dir  -> tail column
+    auto tvcol = [&](int s) { return [=](int h, int i) { int k = vrow(s, h, i); return k < GDB_CFR ? k : (k >= 24 && k < 28 ? GDB_CFR + k - 24 : -1); }; };
+    auto c19 = [&](int s, int base) { return [=](int h, int i) { int k = vrow(s, h, i); return k < GDB_CFR ? base + k : -1; }; };
+    // view_fc reads only dir: W_view column d sits at tv[24+d]
+    p.frag(F_VIEW, PW_VIEW_W, 4, lt(GDB_CFR), [&](int h, int i) { int k = vrow(1, h, i); return (k >= 24 && k < 28) ? k - 24 : -1; });
+    for (int s = 0; s < 2; ++s) {
+        p.frag(F_GVAR + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, GDB_CFR));
+        p.frag(F_GMEAN + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, 2 * GDB_CFR));
+        p.frag(F_GA + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, 0));
+        p.frag(F_FC + s, PW_FC_W, GDB_GF, lt(GDB_IM), [=](int h, int i) { return vrow(s, h, i); });
+    }
+    // [vox | im] vector: k-step 0 = im (16, accumulator order), k-step 1 = vox (element i<4 of half h = channel 4h+i)
+    auto hcol = [&](int s, int base) {
+        return [=](int h, int i) { return s == 0 ? base + GDB_CV + vrow(0, h, i) : (i < 4 ? base + 4 * h + i : -1); };
+    };
+    for (int ot = 0; ot < 2; ++ot)
+        for (int s = 0; s < 2; ++s) {
+            p.frag(F_LR0 + 2 * ot + s, PW_LR0_W, GDB_HD, tile(ot, GDB_HID), hcol(s, 0));
+            p.frag(F_W0B + 2 * ot + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), hcol(s, GDB_HID));
+            p.frag(F_W0C + 2 * ot + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID),
+                   [&, s](int h, int i) { int c = tvcol(s)(h, i); return c >= 0 ? GDB_HID + GDB_HD + c : -1; });
+            for (int xt = 0; xt < 2; ++xt)
+                p.frag(F_W0A + 4 * ot + 2 * xt + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h, int i) { return 32 * xt + vrow(s, h, i); });
+        }
+    // rows 0..7 = feat_head, row 8 = sigma; both read x
+    for (int xt = 0; xt < 2; ++xt)
+        for (int s = 0; s < 2; ++s) {
+            _Float16* f = (_Float16*)(out + (size_t)(F_FH + 2 * xt + s) * 256);
+            for (int l = 0; l < 64; ++l) {
+                int r = l & 31, h = l >> 5;
+                for (int i = 0; i < 8; ++i) {
+                    int col = 32 * xt + vrow(s, h, i);
+                    float v = r < GDB_CV ? fp32[PW_FH_W + r * GDB_HID + col] : (r == GDB_CV ? fp32[PW_SIG_W + col] : 0.f);
+                    f[l * 8 + i] = (_Float16)v;
+                }
+            }
+        }
+    p.table(TB_VIEW, PW_VIEW_B, 1, lt(GDB_CFR));
+    p.table(TB_GLOB, PW_GLOB_B, 1, lt(GDB_GF));
+    p.table(TB_FC, PW_FC_B, 1, lt(GDB_IM));
+    for (int ot = 0; ot < 2; ++ot) {
+        p.table(TB_LR0 + 32 * ot, PW_LR0_B, 1, tile(ot, GDB_HID));
+        p.table(TB_W0 + 32 * ot, PW_W0_B, 1, tile(ot, GDB_HID));
+        p.table(TD_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+            int row = acc_row(r, h);
+            out[TB_FH + h * 16 + r] = row < GDB_CV ? fp32[PW_FH_B + row] : (row == GDB_CV ? fp32[PW_SIG_B] : 0.f);
+        }
+    p.table(TD_AGG, PW_AGG_W, 1, lt(GDB_GF));
+    out[TS_BAGG] = fp32[PW_AGG_B];
+    out[TS_BW2] = fp32[PW_W2_B];
+}
+
+// ---- device side ----------------------------------------------------------------------------
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat
+constexpr int NOUT = NBLEND + GDB_CV;        // 39
+constexpr int STAGE_T = 512;                 // floats: two tail fragments of one view (2 x 1 KiB)
+constexpr int STAGE_B = 1024;                // floats: blend values [31][32]
+constexpr int STAGE_V = STAGE_T + STAGE_B;   // per (wave, view)
+constexpr int COMP_LD = 33;                  // padded bundle stride of the composite staging
+constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
+constexpr int COMP_STRIDE = (COMP_CH * COMP_LD + 3) / 4 * 4;
+
+struct FusedArgs {
+    DevFrame f;
+    const float* pw;  // packed weights (fp32 section, then MFMA section)
+    int row_begin, nrows, nseg, nblk;
+    float* bf; float* depth; float* opac;
+};
+
+__device__ __forceinline__ float to_h_range(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
+
+// k-step S (0/1) of a 32x32 accumulator tile as the next layer's B operand (optionally through ReLU).
+template <int S, bool RELU>
+__device__ __forceinline__ half8 acc_frag(const f32x16& a) {
+    half8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = a[8 * S + i];
+        if (RELU) v = fmaxf(v, 0.f);
+        r[i] = (_Float16)to_h_range(v);
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off, int h) {
+    return *(const f32x16*)(mf + off + h * 16);
+}
+__device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
+    return ((const half8*)(mf + (size_t)idx * 256))[lane];
+}
+__device__ __forceinline__ float dot16_relu(const f32x16& a, const f32x16& w) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = fmaf(fmaxf(a[i], 0.f), w[i], s);
+    return s;
+}
+
+// One mip level, this lane's 16-B chunks only (chunk c = 2*slot + h, slot 0..2).
+__device__ __forceinline__ void tex_level_part(const DevFrame& f, const float* __restrict__ pyr, int l, float u, float v, int h,
+                                               float4 out[3]) {
+    int W = f.lvlW[l], H = f.lvlH[l];
+    int x0, x1, y0, y1; float fx, fy;
+    tex_coord(u, W, x0, x1, fx);
+    tex_coord(v, H, y0, y1, fy);
+    const float* base = pyr + f.lvlOff[l];
+    const float4* a00 = (const float4*)(base + ((size_t)y0 * W + x0) * GDB_CP);
+    const float4* a10 = (const float4*)(base + ((size_t)y0 * W + x1) * GDB_CP);
+    const float4* a01 = (const float4*)(base + ((size_t)y1 * W + x0) * GDB_CP);
+    const float4* a11 = (const float4*)(base + ((size_t)y1 * W + x1) * GDB_CP);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int c = 2 * s + h;
+        if (c < GDB_CP / 4) {
+            float4 top = lerp4(a00[c], a10[c], fx);
+            float4 bot = lerp4(a01[c], a11[c], fx);
+            out[s] = lerp4(top, bot, fy);
+        } else {
+            out[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+extern __shared__ float4 smem4[];
+
+__global__ void __launch_bounds__(256) k_render_fused(FusedArgs a) {
+    const DevFrame& f = a.f;
+    float* smem = (float*)smem4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int V = f.V, S = f.S_max;
+    const float* __restrict__ mf = a.pw + PW_FP32_FLOATS;
+
+    // XCD-aware block order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one
+    // contiguous band of segments so vertically adjacent rows hit the same L2.
+    const int chunk = (a.nblk + 7) >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (lb >= a.nblk) return;  // whole workgroup leaves together
+    const int seg = lb % a.nseg, rr = lb / a.nseg;
+    const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
+    const int x = seg * 32 + j;
+    const bool inrow = x < f.W;
+
+    float* stage = smem + (size_t)wid * V * STAGE_V;
+    float* comp = smem + (size_t)nw * V * STAGE_V;  // [S][COMP_STRIDE]
+    float* alpha_s = comp + (size_t)S * COMP_STRIDE;  // [S][32]
+    float* wn_s = alpha_s + S * 32;                   // [S][32]
+
+    Bundle<4> q;
+    load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
+    const float* tc = tar_cam(f, bi);
+
+    for (int k = wid; k < S; k += nw) {
+        const bool act = inrow && k < q.count;
+        float* ck = comp + (size_t)k * COMP_STRIDE;
+        if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
+            for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
+            if (h == 0) alpha_s[k * 32 + j] = 0.f;
+            continue;
+        }
+        // ---------------- geometry (bundle_sampler.py:246-263) ----------------
+        float z, dn, ball, xyz[4][3], ctr[3];
+        bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);
+
+        // ---------------- voxel feature: channels 4h..4h+3 (bundle_sampler.py:322-324) ----------------
+        float vox[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
+            float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
+            float wx = gx - xf, wy = gy - yf, wz = gz - zf;
+            int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+            const size_t plane = (size_t)f.H * f.W, cstride = plane * f.D;
+            const float* vol = f.feat_volume + ((size_t)bi * GDB_CV + 4 * h) * cstride;
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+                        bool in = xx <= f.W - 1 && yy <= f.H - 1 && zz <= f.D - 1;
+                        float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                        if (!in) wgt = 0.f;
+                        size_t off = ((size_t)min(zz, f.D - 1) * f.H + min(yy, f.H - 1)) * f.W + min(xx, f.W - 1);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vox[c] += vol[c * cstride + off] * wgt;
+                    }
+        }
+
+        // ---------------- pass 1 over views: fetch, g_v, running mean / M2 ----------------
+        f32x16 mean, m2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
+        const f32x16 b_view = load_tab(mf, TB_VIEW, h);
+        const half8 a_view = load_frag(mf, F_VIEW, lane);
+        for (int v = 0; v < V; ++v) {
+            const float* sc = src_cam(f, bi, v);
+            float* st = stage + (size_t)v * STAGE_V;
+            f32x16 tv;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tv[i] = 0.f;
+            float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            if (act) {
+                float cc[3] = {0.f, 0.f, 0.f};
+                float cam[4][3];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        cam[s][r] = sc[S_E + 4 * r] * xyz[s][0] + sc[S_E + 4 * r + 1] * xyz[s][1] + sc[S_E + 4 * r + 2] * xyz[s][2] + sc[S_E + 4 * r + 3];
+                        cc[r] += cam[s][r];
+                    }
+                }
+                const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   bundle_sampler.py:332-337
+                    const float* cm = h ? cam[2 + e] : cam[e];
+                    float im[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cm[0] + sc[S_K + 3 * r + 1] * cm[1] + sc[S_K + 3 * r + 2] * cm[2];
+                    float zc = fmaxf(im[2], 1e-6f);
+                    rgb_fetch(img, f.Ho, f.Wo, 2.f * (im[0] / zc) / (float)f.Wo - 1.f, 2.f * (im[1] / zc) / (float)f.Ho - 1.f, rgb[e]);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) cc[r] = cc[r] / 4.f;
+                float level = mip_level(cc[0], cc[1], cc[2], ball, sc[S_PIXR]);  // :343-348
+                float ci[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ci[r] = sc[S_KS + 3 * r] * cc[0] + sc[S_KS + 3 * r + 1] * cc[1] + sc[S_KS + 3 * r + 2] * cc[2];
+                float zc = fmaxf(ci[2], 1e-6f);
+                float tu = ci[0] / zc / (float)f.W, tvv = ci[1] / zc / (float)f.H;
+                const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
+                int l0, l1; float frac;
+                mip_select(level, f.levels, l0, l1, frac);
+                float4 t0[3];
+                tex_level_part(f, pyr, l0, tu, tvv, h, t0);
+                if (frac > 0.f) {
+                    float4 t1[3];
+                    tex_level_part(f, pyr, l1, tu, tvv, h, t1);
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) t0[s] = lerp4(t0[s], t1[s], frac);
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) { tv[4 * s] = t0[s].x; tv[4 * s + 1] = t0[s].y; tv[4 * s + 2] = t0[s].z; tv[4 * s + 3] = t0[s].w; }
+                // view-direction code   :362-367
+                float td[3], sd[3], dd[3], dif[3], dnn[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - tc[T_O + r];
+                normalize3(dd, td);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - sc[S_C + r];
+                normalize3(dd, sd);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
+                normalize3(dif, dnn);
+                if (h == 0) { tv[12] = dnn[0]; tv[13] = dnn[1]; tv[14] = dnn[2]; tv[15] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2]; }
+            }
+            // stage: blend values (fp32) and the tail fragments (f16)
+            float* bl = st + STAGE_T;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) bl[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int ch = 8 * s + 4 * h + e;
+                    if (ch < GDB_CFR) bl[(12 + ch) * 32 + j] = tv[4 * s + e];
+                }
+            half8 T0 = acc_frag<0, false>(tv), T1 = acc_frag<1, false>(tv);
+            ((half8*)st)[lane] = T0;
+            ((half8*)st)[64 + lane] = T1;
+            // g_v = feat + ReLU(view_fc(dir))   nerf.py:69-71
+            f32x16 g = MFMA(a_view, T1, b_view);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) g[i] = tv[i] + fmaxf(g[i], 0.f);
+#pragma unroll
+            for (int i = 12; i < 16; ++i) g[i] = 0.f;
+            // Welford update of mean / sum of squared deviations over views   nerf.py:73
+            float inv = 1.f / (float)(v + 1);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float d = g[i] - mean[i];
+                mean[i] = fmaf(d, inv, mean[i]);
+                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 var;
+        {
+            float iv = 1.f / (float)(V - 1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) var[i] = m2[i] * iv;
+        }
+        // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
+        f32x16 base = load_tab(mf, TB_GLOB, h);
+        base = MFMA(load_frag(mf, F_GVAR, lane), (acc_frag<0, false>(var)), base);
+        base = MFMA(load_frag(mf, F_GVAR + 1, lane), (acc_frag<1, false>(var)), base);
+        base = MFMA(load_frag(mf, F_GMEAN, lane), (acc_frag<0, false>(mean)), base);
+        base = MFMA(load_frag(mf, F_GMEAN + 1, lane), (acc_frag<1, false>(mean)), base);
+
+        // ---------------- pass 2: per-view global feature, softmax-weighted sum (online) ----------------
+        f32x16 agg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) agg[i] = 0.f;
+        {
+            const f32x16 w_agg = load_tab(mf, TD_AGG, h);
+            const float b_agg = mf[TS_BAGG];
+            const half8 a_ga0 = load_frag(mf, F_GA, lane), a_ga1 = load_frag(mf, F_GA + 1, lane);
+            float mx = -INFINITY, den = 0.f;
+            for (int v = 0; v < V; ++v) {
+                float* st = stage + (size_t)v * STAGE_V;
+                const float* bl = st + STAGE_T;
+                half8 T1 = ((const half8*)st)[64 + lane];
+                f32x16 g = MFMA(a_view, T1, b_view);
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int ch = 8 * s + 4 * h + e;
+                        float fv = ch < GDB_CFR ? bl[(12 + ch) * 32 + j] : 0.f;
+                        g[4 * s + e] = fv + fmaxf(g[4 * s + e], 0.f);
+                    }
+#pragma unroll
+                for (int i = 12; i < 16; ++i) g[i] = 0.f;
+                f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
+                G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
+                float sp = dot16_relu(G, w_agg);
+                float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
+                float mn = fmaxf(mx, sv);
+                float sc_old = __expf(mx - mn), e = __expf(sv - mn);
+                den = den * sc_old + e;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
+                mx = mn;
+            }
+            float r = 1.f / den;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) agg[i] *= r;  // nerf.py:80
+        }
+        // ---------------- geometry branch ----------------
+        f32x16 im = load_tab(mf, TB_FC, h);  // nerf.py:82
+        im = MFMA(load_frag(mf, F_FC, lane), (acc_frag<0, false>(agg)), im);
+        im = MFMA(load_frag(mf, F_FC + 1, lane), (acc_frag<1, false>(agg)), im);
+        const half8 H0 = acc_frag<0, true>(im);  // im, ReLU'd
+        half8 H1;                                // vox channels 4h..4h+3
+#pragma unroll
+        for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+        f32x16 x0 = load_tab(mf, TB_LR0, h), x1 = load_tab(mf, TB_LR0 + 32, h);  // nerf.py:100-101
+        x0 = MFMA(load_frag(mf, F_LR0, lane), H0, x0);
+        x0 = MFMA(load_frag(mf, F_LR0 + 1, lane), H1, x0);
+        x1 = MFMA(load_frag(mf, F_LR0 + 2, lane), H0, x1);
+        x1 = MFMA(load_frag(mf, F_LR0 + 3, lane), H1, x1);
+        const half8 X00 = acc_frag<0, true>(x0), X01 = acc_frag<1, true>(x0);
+        const half8 X10 = acc_frag<0, true>(x1), X11 = acc_frag<1, true>(x1);
+        f32x16 fh = load_tab(mf, TB_FH, h);  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
+        fh = MFMA(load_frag(mf, F_FH, lane), X00, fh);
+        fh = MFMA(load_frag(mf, F_FH + 1, lane), X01, fh);
+        fh = MFMA(load_frag(mf, F_FH + 2, lane), X10, fh);
+        fh = MFMA(load_frag(mf, F_FH + 3, lane), X11, fh);
+        // ---------------- colour branch: shared part of weight.0 ----------------
+        f32x16 hs0 = load_tab(mf, TB_W0, h), hs1 = load_tab(mf, TB_W0 + 32, h);
+        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane), X00, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 1, lane), X01, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 2, lane), X10, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 3, lane), X11, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0B + 0, lane), H0, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0B + 1, lane), H1, hs0);
+        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane), X00, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 5, lane), X01, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 6, lane), X10, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 7, lane), X11, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0B + 2, lane), H0, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0B + 3, lane), H1, hs1);
+
+        // ---------------- pass 3: per-view blend weight, softmax-weighted blend (online) ----------------
+        float bacc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+        {
+            const f32x16 w20 = load_tab(mf, TD_W2, h), w21 = load_tab(mf, TD_W2 + 32, h);
+            const float b_w2 = mf[TS_BW2];
+            const half8 c00 = load_frag(mf, F_W0C + 0, lane), c01 = load_frag(mf, F_W0C + 1, lane);
+            const half8 c10 = load_frag(mf, F_W0C + 2, lane), c11 = load_frag(mf, F_W0C + 3, lane);
+            float mx = -INFINITY, den = 0.f;
+            for (int v = 0; v < V; ++v) {
+                float* st = stage + (size_t)v * STAGE_V;
+                const float* bl = st + STAGE_T;
+                half8 T0 = ((const half8*)st)[lane], T1 = ((const half8*)st)[64 + lane];
+                f32x16 hv0 = MFMA(c00, T0, hs0);
+                hv0 = MFMA(c01, T1, hv0);
+                f32x16 hv1 = MFMA(c10, T0, hs1);
+                hv1 = MFMA(c11, T1, hv1);
+                float up = dot16_relu(hv0, w20) + dot16_relu(hv1, w21);
+                float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
+                float mn = fmaxf(mx, uv);
+                float sc_old = __expf(mx - mn), e = __expf(uv - mn);
+                den = den * sc_old + e;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int c = 16 * h + i;
+                    float val = c < NBLEND ? bl[c * 32 + j] : 0.f;
+                    bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
+                }
+                mx = mn;
+            }
+            float r = 1.f / den;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] *= r;
+        }
+        // ---------------- hand this slot to the composite ----------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int c = 16 * h + i;
+            if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fmaxf(fh[i], 0.f) : 0.f;
+        if (h == 0) {
+            float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
+            ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
+            float sg = softplus_t20(fh[4]);
+            alpha_s[k * 32 + j] = act ? 1.f - __expf(-sg) : 0.f;  // utils.py:34
+        }
+    }
+    __syncthreads();
+    // transmittance weights per bundle, normalised   utils.py:35-41
+    if (threadIdx.x < 32) {
+        float T = 1.f, sum = 0.f;
+        for (int k = 0; k < S; ++k) {
+            float al = alpha_s[k * 32 + threadIdx.x];
+            float w = al * T;
+            T = T * (1.f - al);
+            wn_s[k * 32 + threadIdx.x] = w;
+            sum += w;
+        }
+        float den = fmaxf(sum, 1e-6f);
+        for (int k = 0; k < S; ++k) wn_s[k * 32 + threadIdx.x] = wn_s[k * 32 + threadIdx.x] / den;
+    }
+    __syncthreads();
+    // weighted sums; the segment's (N_b, 39) rows are one contiguous run in memory   utils.py:109-119
+    const int nvalid = min(32, f.W - seg * 32);
+    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
+    for (int qi = threadIdx.x; qi < nvalid * NOUT; qi += blockDim.x) {
+        int jj = qi / NOUT, c = qi - jj * NOUT;
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) acc += comp[(size_t)k * COMP_STRIDE + c * COMP_LD + jj] * wn_s[k * 32 + jj];
+        a.bf[b0 * NOUT + qi] = acc;
+    }
+    if (threadIdx.x < 64) {
+        int jj = threadIdx.x & 31, which = threadIdx.x >> 5;
+        if (jj < nvalid) {
+            float acc = 0.f;
+            for (int k = 0; k < S; ++k) {
+                float w = wn_s[k * 32 + jj];
+                acc += which ? w : comp[(size_t)k * COMP_STRIDE + NOUT * COMP_LD + jj] * w;
+            }
+            if (which) a.opac[b0 + jj] = acc;
+            else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
+        }
+    }
+}
+
+extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
+                                        int32_t row_begin, int32_t row_end, int32_t precision, float* bf, float* depth,
+                                        float* opac, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, fr, true); if (rc) return rc;
+    if (!ws || !pw || !bf || !depth || !opac) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
+    if (precision != 0) return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA, f32 accumulate)", precision);
+    // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
+    if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
+    if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
+    if (row_begin == row_end) return GDB_OK;
+    WsLayout L = ws_layout(*cfg, *fr);
+    FusedArgs a;
+    a.f = dev_frame(*cfg, *fr, L, ws);
+    a.pw = pw;
+    a.row_begin = row_begin; a.nrows = row_end - row_begin;
+    a.nseg = (fr->W + 31) / 32;
+    a.nblk = fr->B * a.nrows * a.nseg;
+    a.bf = bf; a.depth = depth; a.opac = opac;
+    const int S = cfg->max_num_samples, V = fr->V;
+    const size_t fixed = sizeof(float) * ((size_t)S * COMP_STRIDE + 2 * (size_t)S * 32);
+    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
+    const size_t lds_max = 160 * 1024;
+    // at most 4 waves per workgroup (one per SIMD); with more slots than waves each wave loops
+    int nw = S <= 4 ? S : (S + (S + 3) / 4 - 1) / ((S + 3) / 4);
+    while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
+    size_t lds = fixed + nw * per_wave;
+    if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = lds_max;
+    }
+    unsigned grid = (unsigned)((a.nblk + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_render_fused, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
+    return GDB_OK;
 }

@@ -49,7 +49,7 @@ extern "C" int gdb_pack_weights(const GdbConfig* cfg, const float* const t[18], 
 // ============================================================================================
 // A5  MLP, fp32
 // ============================================================================================
-__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ float relu(float x) { return x < 0.f ? 0.f : x; }  // NaN stays NaN, as torch's ReLU
 
 // g_v = feat19 + ReLU(W_view dir + b)      nerf.py:69-71
 __device__ __forceinline__ void view_feat(const float* __restrict__ pw, int viewdir, const float* __restrict__ tail,

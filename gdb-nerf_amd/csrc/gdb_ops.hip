@@ -263,69 +263,6 @@ extern "C" int gdb_build_rays(const GdbConfig* cfg, const GdbFrame* f, const voi
 // ============================================================================================
 // A2+A3  sample
 // ============================================================================================
-// Geometry of one bundle, shared by the mirror below and by the fused kernel.
-template <int BB>  // BB = b*b
-struct Bundle {
-    float o[3];
-    float d[BB][3];    // sub-ray directions, order by*b+bx            bundle_sampler.py:100
-    float u, v;        // mean normalised pixel coordinate              :104
-    float nearv, farv, vnear, vfar;
-    float unit;        // sphere radius per unit distance               :262
-    int count;
-};
-
-template <int BB>
-__device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
-    constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
-    const float* tc = tar_cam(f, bi);
-    float sum[3] = {0.f, 0.f, 0.f};
-    float su = 0.f, sv = 0.f;
-#pragma unroll
-    for (int by = 0; by < b; ++by)
-#pragma unroll
-        for (int bx = 0; bx < b; ++bx) {
-            float x = (float)(w * b + bx) + 0.5f, y = (float)(h * b + by) + 0.5f;
-            ray_dir(tc + T_M, x, y, q.d[by * b + bx]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sum[i] += q.d[by * b + bx][i];
-            su += 2.f * x / (float)f.Wo - 1.f;
-            sv += 2.f * y / (float)f.Ho - 1.f;
-        }
-    float md[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { md[i] = sum[i] / (float)BB; q.o[i] = tc[T_O + i]; }
-    q.u = su / (float)BB; q.v = sv / (float)BB;
-    float nrm = sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
-    float cosv = (md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2]) / nrm;
-    q.unit = ball_unit(tc[T_DISK], cosv);
-    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
-    float n0 = f.depth_range[((size_t)bi * 2) * hw + p], f0 = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
-    float vn = f.vol_range[((size_t)bi * 2) * hw + p], vf = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
-    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226
-    q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
-    q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
-}
-
-// One sample of a bundle: mid depth, normalised volume depth, sub-ray points, sphere radius.
-template <int BB>
-__device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB>& q, int k, float& z, float& dnorm,
-                                              float xyz[BB][3], float ctr[3], float& ball) {
-    float step = (q.farv - q.nearv) / (float)q.count;
-    float t0 = q.nearv + step * (float)k, t1 = q.nearv + step * (float)(k + 1);  // :183
-    z = 0.5f * (t0 + t1);                                                        // :246
-    dnorm = 2.f * (z - q.vnear) / (q.vfar - q.vnear) - 1.f;                      // :247
-    if (f.inv_depth) z = 1.f / z;                                                // :250-251
-    float s[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < BB; ++r)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { xyz[r][i] = q.o[i] + q.d[r][i] * z; s[i] += xyz[r][i]; }  // :255
-    float dd = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { ctr[i] = s[i] / (float)BB; float e = ctr[i] - q.o[i]; dd += e * e; }  // :256,:259
-    ball = sqrtf(dd) * q.unit;                                                   // :263
-}
-
 template <int BB>
 __global__ void k_counts(DevFrame f, int32_t* __restrict__ cnt) {
     size_t nb = (size_t)f.B * f.H * f.W;
@@ -525,29 +462,6 @@ __device__ __forceinline__ void tex_fetch(const DevFrame& f, const float* __rest
 #pragma unroll
         for (int c = 0; c < GDB_CP / 4; ++c) out[c] = lerp4(out[c], o1[c], frac);
     }
-}
-
-// Bilinear RGB at a projected point: 4-D grid_sample, border, align_corners=False.  :336
-__device__ __forceinline__ void rgb_fetch(const float* __restrict__ img, int Ho, int Wo, float gx, float gy, float rgb[3]) {
-    float x = gs_coord(gx, Wo), y = gs_coord(gy, Ho);
-    float xf = floorf(x), yf = floorf(y);
-    float wx = x - xf, wy = y - yf, ex = 1.f - wx, ey = 1.f - wy;
-    int x0 = (int)xf, y0 = (int)yf;
-    bool inx = x0 + 1 <= Wo - 1, iny = y0 + 1 <= Ho - 1;
-    int x1 = min(x0 + 1, Wo - 1), y1 = min(y0 + 1, Ho - 1);
-    float w00 = ex * ey, w10 = inx ? wx * ey : 0.f, w01 = iny ? ex * wy : 0.f, w11 = (inx && iny) ? wx * wy : 0.f;
-    size_t plane = (size_t)Ho * Wo;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* p = img + c * plane;
-        rgb[c] = p[(size_t)y0 * Wo + x0] * w00 + p[(size_t)y0 * Wo + x1] * w10 + p[(size_t)y1 * Wo + x0] * w01 +
-                 p[(size_t)y1 * Wo + x1] * w11;
-    }
-}
-
-__device__ __forceinline__ void normalize3(const float a[3], float o[3]) {  // F.normalize, eps 1e-12
-    float n = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
-    o[0] = a[0] / n; o[1] = a[1] / n; o[2] = a[2] / n;
 }
 
 // One (view, sample): per-sub-ray RGB, mip-mapped feature, view-direction code.  :327-369

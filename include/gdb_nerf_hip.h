@@ -16,8 +16,9 @@
  *    synchronises with the host.  Data-dependent sample counts stay on the device.
  *  - Return value: GDB_OK (0) or a negative GdbStatus; gdb_last_error() returns a
  *    thread-local message for the last failure on the calling thread.  Shape / config
- *    violations are rejected before any launch.  Kernels are NaN-transparent like the
- *    reference.
+ *    violations are rejected before any launch.  The operator mirrors are NaN-transparent
+ *    like the reference; the fused kernel converts activations to f16 with a clamp to the
+ *    finite f16 range, which does not preserve NaN.
  */
 #ifndef GDB_NERF_HIP_H
 #define GDB_NERF_HIP_H

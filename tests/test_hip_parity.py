@@ -7,7 +7,7 @@ Tolerances (float32, absolute unless stated):
   * unit-scale values fetched by interpolation / MLP outputs, fp32 kernels: 2e-4 (the source
     of difference is summation order and the 1-ulp freedom of the camera inverses, amplified
     by white-noise feature gradients);
-  * fused fp16-MFMA kernel: 2e-2 abs on bundle_feat, PSNR delta <= 0.05 dB (north_star).
+  * fused fp16-MFMA kernel: 2e-3 abs on bundle_feat, PSNR delta <= 0.05 dB (north_star).
 """
 import numpy as np
 import pytest
@@ -174,3 +174,103 @@ def test_engine_rejects_bad_shapes():
         eng.prepare(bad)
     with pytest.raises(ValueError, match="power of 2"):
         HotPathEngine(bundle_size=3)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused production kernel (f16 MFMA MLP, f32 accumulate, f32 fetch / composite)
+# ---------------------------------------------------------------------------------------------
+FUSED_TOL = 2e-3  # abs, on O(1) bundle features; observed ~2e-4 max / 1.4e-5 rms (printed by the tests)
+
+
+def _psnr_delta(bf_a, bf_b, H, W):
+    """PSNR of the fine RGB (first 12 channels pixel-shuffled to an image, network.py:175) of both
+    renders against one synthetic ground truth (oracle render + fixed noise); north_star bar 0.05 dB."""
+    def img(bf):
+        x = bf[:, :12].reshape(-1, H, W, 3, 2, 2)            # (B,H,W,c,by,bx)
+        return np.transpose(x, (0, 1, 4, 2, 5, 3)).reshape(-1, 2 * H, 2 * W, 3)
+    a, b = img(bf_a), img(bf_b)
+    gt = np.clip(b + np.random.default_rng(0).normal(0, 0.03, b.shape), 0, 1)
+    return abs(oracle.psnr(gt.reshape(-1, gt.shape[2], 3), a.reshape(-1, a.shape[2], 3)) -
+               oracle.psnr(gt.reshape(-1, gt.shape[2], 3), b.reshape(-1, b.shape[2], 3)))
+
+
+@pytest.mark.parametrize("tag", ["dtu", "mips"])
+def test_fused_vs_golden(tag):
+    fx = load_golden("F6_hotpath_" + tag)
+    eng = engine_for(frame_of(fx), nerf_weights_of(fx), max_num_samples=int(fx["S_max"]),
+                     is_adaptive=bool(fx["adaptive"]), inv_depth=bool(fx["inv_depth"]))
+    bf, depth, opac = eng.render()
+    e = max_abs(npy(bf), fx["bundle_feat"])
+    print(f"fused vs reference fixture {tag}: max abs err {e:.3e}")
+    assert e <= FUSED_TOL
+    assert max_abs(npy(depth), fx["depth"]) <= 2e-3 * float(np.abs(fx["depth"]).max())
+    assert max_abs(npy(opac), fx["opacity"]) <= 1e-5
+
+
+@pytest.mark.parametrize("Ho,Wo,V,B,S,adaptive,inv,scene", [
+    (64, 80, 3, 1, 3, True, False, "dtu"),     # c1
+    (64, 80, 3, 1, 6, False, False, "dtu"),    # fixed count, waves loop over slots
+    (96, 72, 4, 2, 6, True, True, "nerf"),     # ragged row (W=36), batch 2, disparity sampling
+    (48, 80, 2, 1, 3, True, False, "llff"),
+    (32, 64, 5, 1, 8, True, False, "dtu"),     # 5 views, 8 slots
+])
+def test_fused_vs_oracle(Ho, Wo, V, B, S, adaptive, inv, scene):
+    frame = synthetic.make_frame(Ho, Wo, V=V, B=B, scene=scene, seed=21, src_focal_scale=(1.0, 1.9, 3.3))
+    w = synthetic.make_nerf_weights(seed=5)
+    with np.errstate(all="ignore"):
+        obf, od, oo = oracle.hot_path(frame, w, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    eng = engine_for(frame, w, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    bf, depth, opac = eng.render()
+    e = max_abs(npy(bf), obf)
+    print(f"fused vs oracle {Ho}x{Wo} V{V} S{S}: max abs err {e:.3e}, rms {np.sqrt(np.mean((npy(bf)-obf)**2)):.3e}")
+    assert e <= FUSED_TOL
+    assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max())
+    assert max_abs(npy(opac), oo) <= 1e-5
+    assert _psnr_delta(npy(bf), obf, Ho // 2, Wo // 2) <= 0.05
+
+
+def test_fused_matches_unfused_at_full_size():
+    """c2 (BASELINE.json configs[1]) is too big for the oracle in a test; at full size the fused kernel is
+    checked against the fp32 operator chain, itself oracle-checked above, plus size-independent properties."""
+    frame = synthetic.make_frame(512, 640, V=3, seed=0)
+    w = synthetic.make_nerf_weights(seed=0)
+    eng = engine_for(frame, w, max_num_samples=3, is_adaptive=True)
+    bf, depth, opac = eng.render()
+    ubf, ud, uo = eng.render_unfused()
+    e = max_abs(npy(bf), npy(ubf))
+    print(f"fused vs fp32 chain at 512x640: max abs err {e:.3e}")
+    assert e <= FUSED_TOL
+    assert max_abs(npy(depth), npy(ud)) <= 2e-3 * 905.0
+    # normalised weights sum to one; depth stays inside the prior
+    assert float((opac - 1).abs().max()) <= 1e-5
+    dr = frame["depth_range"][0]
+    d = npy(depth).reshape(256, 320)
+    assert np.all(d >= dr[0] - 1e-2) and np.all(d <= dr[1] + 1e-2)
+    assert _psnr_delta(npy(bf), npy(ubf), 256, 320) <= 0.05
+
+
+def test_fused_row_strips_tile_the_frame():
+    """Row-strip launches (the multi-GPU shard unit) reproduce the full-frame launch bit for bit."""
+    frame = synthetic.make_frame(64, 80, V=3, B=2, seed=4)
+    w = synthetic.make_nerf_weights(seed=1)
+    eng = engine_for(frame, w)
+    full = [t.clone() for t in eng.render()]
+    nb = eng.n_bundles
+    out = (torch.zeros((nb, eng.Q), device="cuda"), torch.zeros(nb, device="cuda"), torch.zeros(nb, device="cuda"))
+    for r0, r1 in ((0, 5), (5, 6), (6, 32)):
+        eng.render(r0, r1, 0, out)
+    for a, b in zip(full, out):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="row strip"):
+        eng.render(3, 40)
+
+
+def test_single_view_is_rejected_by_fused_and_nan_in_mirror():
+    """One source view: the reference's unbiased variance over views (nerf.py:73) is NaN and so is
+    everything after it.  The fp32 mirror reproduces the NaN; the fused entry refuses the shape."""
+    frame = synthetic.make_frame(32, 64, V=1, seed=2)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=5), max_num_samples=2, is_adaptive=False)
+    with pytest.raises(ValueError, match="2 source views"):
+        eng.render()
+    bf, _, _ = eng.render_unfused()
+    assert torch.isnan(bf).all()
