@@ -156,21 +156,26 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 }
 
 // ---- device side ----------------------------------------------------------------------------
+// Compiler-only fence: weight fragments are loop-invariant global loads, and without it hipcc
+// hoists all 33 of them (132 VGPRs) to kernel entry.
+#define PHASE_FENCE() asm volatile("" ::: "memory")
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
 constexpr int STAGE_T = 512;                 // floats: two tail fragments of one view (2 x 1 KiB)
-constexpr int STAGE_B = 1024;                // floats: blend values [31][32]
+constexpr int STAGE_B = NBLEND * 32;         // floats: blend values [31][32]
 constexpr int STAGE_V = STAGE_T + STAGE_B;   // per (wave, view)
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite staging
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
-constexpr int COMP_STRIDE = (COMP_CH * COMP_LD + 3) / 4 * 4;
+constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
+constexpr int COMP_WN = COMP_ALPHA + 32;                     // normalised weight [32]
+constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot record
 
 struct FusedArgs {
     DevFrame f;
     const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nblk;
+    int row_begin, nrows, nseg, nblk, alias;
     float* bf; float* depth; float* opac;
 };
 
@@ -189,12 +194,17 @@ __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
     return r;
 }
 
+// Weight fragments / tables are addressed as (uniform base + constant) + per-lane offset.  The
+// per-lane part goes through an opaque asm once per phase: otherwise hipcc materialises all ~45
+// 64-bit per-lane addresses at kernel entry (loop-invariant) and spills them.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off, int h) {
     return *(const f32x16*)(mf + off + h * 16);
 }
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
     return ((const half8*)(mf + (size_t)idx * 256))[lane];
 }
+#define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5
 __device__ __forceinline__ float dot16_relu(const f32x16& a, const f32x16& w) {
     float s = 0.f;
 #pragma unroll
@@ -229,7 +239,328 @@ __device__ __forceinline__ void tex_level_part(const DevFrame& f, const float* _
 
 extern __shared__ float4 smem4[];
 
-__global__ void __launch_bounds__(256) k_render_fused(FusedArgs a) {
+// g_v = feat ⊕ rgb + ReLU(view_fc(dir)) of one staged view, in accumulator layout   nerf.py:69-71
+__device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const half8 a_view, const f32x16& b_view,
+                                         int lane, int j, int h) {
+    const float* bl = st + STAGE_T;
+    half8 T1 = ((const half8*)st)[64 + lane];
+    f32x16 g = MFMA(a_view, T1, b_view);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int ch = 8 * s + 4 * h + e;
+            float fv = ch < GDB_CFR ? bl[(12 + ch) * 32 + j] : 0.f;
+            g[4 * s + e] = fv + fmaxf(g[4 * s + e], 0.f);
+        }
+#pragma unroll
+    for (int i = 12; i < 16; ++i) g[i] = 0.f;
+    return g;
+}
+
+// Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
+// chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
+__device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[4][3], const float ctr[3],
+                                            float ball, const float* __restrict__ tc, f32x16& tv, float rgb[2][3]) {
+    const float* sc = src_cam(f, bi, v);
+    float cc[3] = {0.f, 0.f, 0.f};
+    float cam[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            cam[s][r] = sc[S_E + 4 * r] * xyz[s][0] + sc[S_E + 4 * r + 1] * xyz[s][1] + sc[S_E + 4 * r + 2] * xyz[s][2] + sc[S_E + 4 * r + 3];
+            cc[r] += cam[s][r];
+        }
+    const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :332-337
+        const float* cm = h ? cam[2 + e] : cam[e];
+        float im[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cm[0] + sc[S_K + 3 * r + 1] * cm[1] + sc[S_K + 3 * r + 2] * cm[2];
+        float zc = fmaxf(im[2], 1e-6f);
+        rgb_fetch(img, f.Ho, f.Wo, 2.f * (im[0] / zc) / (float)f.Wo - 1.f, 2.f * (im[1] / zc) / (float)f.Ho - 1.f, rgb[e]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cc[r] = cc[r] / 4.f;
+    float level = mip_level(cc[0], cc[1], cc[2], ball, sc[S_PIXR]);  // :343-348
+    float ci[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ci[r] = sc[S_KS + 3 * r] * cc[0] + sc[S_KS + 3 * r + 1] * cc[1] + sc[S_KS + 3 * r + 2] * cc[2];
+    float zc = fmaxf(ci[2], 1e-6f);
+    float tu = ci[0] / zc / (float)f.W, tvv = ci[1] / zc / (float)f.H;
+    const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
+    int l0, l1; float frac;
+    mip_select(level, f.levels, l0, l1, frac);
+    float4 t0[3];
+    tex_level_part(f, pyr, l0, tu, tvv, h, t0);
+    if (frac > 0.f) {
+        float4 t1[3];
+        tex_level_part(f, pyr, l1, tu, tvv, h, t1);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t0[s] = lerp4(t0[s], t1[s], frac);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { tv[4 * s] = t0[s].x; tv[4 * s + 1] = t0[s].y; tv[4 * s + 2] = t0[s].z; tv[4 * s + 3] = t0[s].w; }
+    // view-direction code   :362-367
+    float td[3], sd[3], dd[3], dif[3], dnn[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - tc[T_O + r];
+    normalize3(dd, td);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - sc[S_C + r];
+    normalize3(dd, sd);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
+    normalize3(dif, dnn);
+    if (h == 0) { tv[12] = dnn[0]; tv[13] = dnn[1]; tv[14] = dnn[2]; tv[15] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2]; }
+}
+
+// One sample slot k of the workgroup's 32 bundles: gather, MLP, record for the composite.
+__device__ __forceinline__ void render_slot(const DevFrame& f, const float* __restrict__ mf, float* __restrict__ stage,
+                                            float* __restrict__ ck, const float* __restrict__ tc, int k, int bi, int row,
+                                            int x, bool inrow, int lane, int j, int h) {
+    const int V = f.V;
+    {
+        float z;
+        bool act;
+        half8 H1;  // vox channels 4h..4h+3 as the k-step-1 operand of [vox | im]
+        // ======================= gather: all a view contributes goes to LDS =======================
+        {
+            Bundle<4> q;
+            load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
+            act = inrow && k < q.count;
+            if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
+                for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
+                if (h == 0) ck[COMP_ALPHA + j] = 0.f;
+                return;
+            }
+            float dn, ball, xyz[4][3], ctr[3];
+            bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
+
+            float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
+            if (act) {
+                float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
+                float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
+                float wx = gx - xf, wy = gy - yf, wz = gz - zf;
+                int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+                const size_t plane = (size_t)f.H * f.W, cs = plane * f.D;
+                const float* vol = f.feat_volume + ((size_t)bi * GDB_CV + 4 * h) * cs;
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+                            bool in = xx <= f.W - 1 && yy <= f.H - 1 && zz <= f.D - 1;
+                            float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                            if (!in) wgt = 0.f;
+                            size_t off = ((size_t)min(zz, f.D - 1) * f.H + min(yy, f.H - 1)) * f.W + min(xx, f.W - 1);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) vox[c] += vol[c * cs + off] * wgt;
+                        }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+
+            for (int v = 0; v < V; ++v) {
+                float* st = stage + (size_t)v * STAGE_V;
+                f32x16 tv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tv[i] = 0.f;
+                float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+                if (act) gather_view(f, bi, v, h, xyz, ctr, ball, tc, tv, rgb);
+                float* bl = st + STAGE_T;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) bl[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int ch = 8 * s + 4 * h + e;
+                        if (ch < GDB_CFR) bl[(12 + ch) * 32 + j] = tv[4 * s + e];
+                    }
+                ((half8*)st)[lane] = acc_frag<0, false>(tv);
+                ((half8*)st)[64 + lane] = acc_frag<1, false>(tv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        PHASE_FENCE();
+        // ======================= MLP (nerf.py:58-115) =======================
+        f32x16 base;
+        {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+            f32x16 mean, m2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
+            const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
+            const half8 a_view = load_frag(mf, F_VIEW, lane_o);
+            for (int v = 0; v < V; ++v) {
+                f32x16 g = view_g(stage + (size_t)v * STAGE_V, a_view, b_view, lane, j, h);
+                float inv = 1.f / (float)(v + 1);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    float d = g[i] - mean[i];
+                    mean[i] = fmaf(d, inv, mean[i]);
+                    m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
+                }
+            }
+            float iv = 1.f / (float)(V - 1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
+            // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
+            base = load_tab(mf, TB_GLOB, h_o);
+            base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), base);
+            base = MFMA(load_frag(mf, F_GVAR + 1, lane_o), (acc_frag<1, false>(m2)), base);
+            base = MFMA(load_frag(mf, F_GMEAN, lane_o), (acc_frag<0, false>(mean)), base);
+            base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
+        }
+        PHASE_FENCE();
+        half8 H0;
+        {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
+            f32x16 agg;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) agg[i] = 0.f;
+            const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
+            const half8 a_view = load_frag(mf, F_VIEW, lane_o);
+            const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
+            const float b_agg = mf[TS_BAGG];
+            float mx = -INFINITY, den = 0.f;
+            for (int v = 0; v < V; ++v) {
+                f32x16 g = view_g(stage + (size_t)v * STAGE_V, a_view, b_view, lane, j, h);
+                f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
+                G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
+                float sp = dot16_relu(G, load_tab(mf, TD_AGG, h_o));
+                float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
+                float mn = fmaxf(mx, sv);
+                float sc_old = __expf(mx - mn), e = __expf(sv - mn);
+                den = den * sc_old + e;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
+                mx = mn;
+            }
+            float r = 1.f / den;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) agg[i] *= r;
+            PHASE_FENCE();
+            const int lane_o2 = opaque(lane), h_o2 = lane_o2 >> 5;
+            f32x16 im = load_tab(mf, TB_FC, h_o2);  // nerf.py:82
+            im = MFMA(load_frag(mf, F_FC, lane_o2), (acc_frag<0, false>(agg)), im);
+            im = MFMA(load_frag(mf, F_FC + 1, lane_o2), (acc_frag<1, false>(agg)), im);
+            H0 = acc_frag<0, true>(im);
+        }
+        PHASE_FENCE();
+        half8 X00, X01, X10, X11;
+        {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
+            f32x16 x0 = load_tab(mf, TB_LR0, h_o);
+            x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, x0);
+            x0 = MFMA(load_frag(mf, F_LR0 + 1, lane_o), H1, x0);
+            X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
+            f32x16 x1 = load_tab(mf, TB_LR0 + 32, h_o);
+            x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, x1);
+            x1 = MFMA(load_frag(mf, F_LR0 + 3, lane_o), H1, x1);
+            X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
+        }
+        PHASE_FENCE();
+        float fhv[4], sig;
+        {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
+            f32x16 fh = load_tab(mf, TB_FH, h_o);
+            fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
+            fh = MFMA(load_frag(mf, F_FH + 1, lane_o), X01, fh);
+            fh = MFMA(load_frag(mf, F_FH + 2, lane_o), X10, fh);
+            fh = MFMA(load_frag(mf, F_FH + 3, lane_o), X11, fh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fhv[i] = fmaxf(fh[i], 0.f);
+            sig = fh[4];
+        }
+        PHASE_FENCE();
+        // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
+        f32x16 hs0, hs1;
+        {   LANE_KEYS();
+        hs0 = load_tab(mf, TB_W0, h_o);
+        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane_o), X00, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 1, lane_o), X01, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 2, lane_o), X10, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 3, lane_o), X11, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0B + 0, lane_o), H0, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0B + 1, lane_o), H1, hs0);
+        }
+        PHASE_FENCE();
+        {   LANE_KEYS();
+        hs1 = load_tab(mf, TB_W0 + 32, h_o);
+        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane_o), X00, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 5, lane_o), X01, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 6, lane_o), X10, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 7, lane_o), X11, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0B + 2, lane_o), H0, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0B + 3, lane_o), H1, hs1);
+        }
+        PHASE_FENCE();
+        // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
+        float bacc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+        {
+            const float b_w2 = mf[TS_BW2];
+            float mx = -INFINITY, den = 0.f;
+            for (int v = 0; v < V; ++v) {
+                LANE_KEYS();
+                const float* st = stage + (size_t)v * STAGE_V;
+                const float* bl = st + STAGE_T;
+                half8 T0 = ((const half8*)st)[lane], T1 = ((const half8*)st)[64 + lane];
+                float up;
+                {
+                    f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), T0, hs0);
+                    hv = MFMA(load_frag(mf, F_W0C + 1, lane_o), T1, hv);
+                    up = dot16_relu(hv, load_tab(mf, TD_W2, h_o));
+                }
+                {
+                    f32x16 hv = MFMA(load_frag(mf, F_W0C + 2, lane_o), T0, hs1);
+                    hv = MFMA(load_frag(mf, F_W0C + 3, lane_o), T1, hv);
+                    up += dot16_relu(hv, load_tab(mf, TD_W2 + 32, h_o));
+                }
+                float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
+                float mn = fmaxf(mx, uv);
+                float sc_old = __expf(mx - mn), e = __expf(uv - mn);
+                den = den * sc_old + e;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int c = 16 * h + i;
+                    float val = c < NBLEND ? bl[c * 32 + j] : 0.f;
+                    bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
+                }
+                mx = mn;
+                PHASE_FENCE();
+            }
+            float r = 1.f / den;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] *= r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        PHASE_FENCE();
+        // ======================= hand this slot to the composite =======================
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int c = 16 * h + i;
+            if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fhv[i] : 0.f;
+        if (h == 0) {
+            float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
+            ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
+            ck[COMP_ALPHA + j] = act ? 1.f - __expf(-softplus_t20(sig)) : 0.f;  // utils.py:34
+        }
+        }
+}
+
+template <bool LOOP>
+__global__ void __launch_bounds__(256, 3) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -247,304 +578,40 @@ __global__ void __launch_bounds__(256) k_render_fused(FusedArgs a) {
     const int x = seg * 32 + j;
     const bool inrow = x < f.W;
 
-    float* stage = smem + (size_t)wid * V * STAGE_V;
-    float* comp = smem + (size_t)nw * V * STAGE_V;  // [S][COMP_STRIDE]
-    float* alpha_s = comp + (size_t)S * COMP_STRIDE;  // [S][32]
-    float* wn_s = alpha_s + S * 32;                   // [S][32]
-
-    Bundle<4> q;
-    load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
+    // LDS: per-wave staging [V][STAGE_V], then (unless aliased) composite staging.  When every
+    // wave owns exactly one slot (S == nw) the composite record of slot k — values [40][33],
+    // alpha [32], normalised weight [32] — reuses wave k's own staging area, dead by then.
+    const size_t wave_fl = (size_t)V * STAGE_V;
+    float* stage = smem + (size_t)wid * wave_fl;
+    const bool alias = a.alias != 0;
+    const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
+    float* rec0 = alias ? smem : smem + (size_t)nw * wave_fl;
     const float* tc = tar_cam(f, bi);
 
-    for (int k = wid; k < S; k += nw) {
-        const bool act = inrow && k < q.count;
-        float* ck = comp + (size_t)k * COMP_STRIDE;
-        if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
-            for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
-            if (h == 0) alpha_s[k * 32 + j] = 0.f;
-            continue;
-        }
-        // ---------------- geometry (bundle_sampler.py:246-263) ----------------
-        float z, dn, ball, xyz[4][3], ctr[3];
-        bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);
-
-        // ---------------- voxel feature: channels 4h..4h+3 (bundle_sampler.py:322-324) ----------------
-        float vox[4] = {0.f, 0.f, 0.f, 0.f};
-        if (act) {
-            float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
-            float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
-            float wx = gx - xf, wy = gy - yf, wz = gz - zf;
-            int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
-            const size_t plane = (size_t)f.H * f.W, cstride = plane * f.D;
-            const float* vol = f.feat_volume + ((size_t)bi * GDB_CV + 4 * h) * cstride;
-#pragma unroll
-            for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-                        bool in = xx <= f.W - 1 && yy <= f.H - 1 && zz <= f.D - 1;
-                        float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                        if (!in) wgt = 0.f;
-                        size_t off = ((size_t)min(zz, f.D - 1) * f.H + min(yy, f.H - 1)) * f.W + min(xx, f.W - 1);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) vox[c] += vol[c * cstride + off] * wgt;
-                    }
-        }
-
-        // ---------------- pass 1 over views: fetch, g_v, running mean / M2 ----------------
-        f32x16 mean, m2;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-        const f32x16 b_view = load_tab(mf, TB_VIEW, h);
-        const half8 a_view = load_frag(mf, F_VIEW, lane);
-        for (int v = 0; v < V; ++v) {
-            const float* sc = src_cam(f, bi, v);
-            float* st = stage + (size_t)v * STAGE_V;
-            f32x16 tv;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tv[i] = 0.f;
-            float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            if (act) {
-                float cc[3] = {0.f, 0.f, 0.f};
-                float cam[4][3];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        cam[s][r] = sc[S_E + 4 * r] * xyz[s][0] + sc[S_E + 4 * r + 1] * xyz[s][1] + sc[S_E + 4 * r + 2] * xyz[s][2] + sc[S_E + 4 * r + 3];
-                        cc[r] += cam[s][r];
-                    }
-                }
-                const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   bundle_sampler.py:332-337
-                    const float* cm = h ? cam[2 + e] : cam[e];
-                    float im[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cm[0] + sc[S_K + 3 * r + 1] * cm[1] + sc[S_K + 3 * r + 2] * cm[2];
-                    float zc = fmaxf(im[2], 1e-6f);
-                    rgb_fetch(img, f.Ho, f.Wo, 2.f * (im[0] / zc) / (float)f.Wo - 1.f, 2.f * (im[1] / zc) / (float)f.Ho - 1.f, rgb[e]);
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) cc[r] = cc[r] / 4.f;
-                float level = mip_level(cc[0], cc[1], cc[2], ball, sc[S_PIXR]);  // :343-348
-                float ci[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) ci[r] = sc[S_KS + 3 * r] * cc[0] + sc[S_KS + 3 * r + 1] * cc[1] + sc[S_KS + 3 * r + 2] * cc[2];
-                float zc = fmaxf(ci[2], 1e-6f);
-                float tu = ci[0] / zc / (float)f.W, tvv = ci[1] / zc / (float)f.H;
-                const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
-                int l0, l1; float frac;
-                mip_select(level, f.levels, l0, l1, frac);
-                float4 t0[3];
-                tex_level_part(f, pyr, l0, tu, tvv, h, t0);
-                if (frac > 0.f) {
-                    float4 t1[3];
-                    tex_level_part(f, pyr, l1, tu, tvv, h, t1);
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) t0[s] = lerp4(t0[s], t1[s], frac);
-                }
-#pragma unroll
-                for (int s = 0; s < 3; ++s) { tv[4 * s] = t0[s].x; tv[4 * s + 1] = t0[s].y; tv[4 * s + 2] = t0[s].z; tv[4 * s + 3] = t0[s].w; }
-                // view-direction code   :362-367
-                float td[3], sd[3], dd[3], dif[3], dnn[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - tc[T_O + r];
-                normalize3(dd, td);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - sc[S_C + r];
-                normalize3(dd, sd);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
-                normalize3(dif, dnn);
-                if (h == 0) { tv[12] = dnn[0]; tv[13] = dnn[1]; tv[14] = dnn[2]; tv[15] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2]; }
-            }
-            // stage: blend values (fp32) and the tail fragments (f16)
-            float* bl = st + STAGE_T;
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) bl[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int ch = 8 * s + 4 * h + e;
-                    if (ch < GDB_CFR) bl[(12 + ch) * 32 + j] = tv[4 * s + e];
-                }
-            half8 T0 = acc_frag<0, false>(tv), T1 = acc_frag<1, false>(tv);
-            ((half8*)st)[lane] = T0;
-            ((half8*)st)[64 + lane] = T1;
-            // g_v = feat + ReLU(view_fc(dir))   nerf.py:69-71
-            f32x16 g = MFMA(a_view, T1, b_view);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) g[i] = tv[i] + fmaxf(g[i], 0.f);
-#pragma unroll
-            for (int i = 12; i < 16; ++i) g[i] = 0.f;
-            // Welford update of mean / sum of squared deviations over views   nerf.py:73
-            float inv = 1.f / (float)(v + 1);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                float d = g[i] - mean[i];
-                mean[i] = fmaf(d, inv, mean[i]);
-                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x16 var;
-        {
-            float iv = 1.f / (float)(V - 1);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) var[i] = m2[i] * iv;
-        }
-        // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-        f32x16 base = load_tab(mf, TB_GLOB, h);
-        base = MFMA(load_frag(mf, F_GVAR, lane), (acc_frag<0, false>(var)), base);
-        base = MFMA(load_frag(mf, F_GVAR + 1, lane), (acc_frag<1, false>(var)), base);
-        base = MFMA(load_frag(mf, F_GMEAN, lane), (acc_frag<0, false>(mean)), base);
-        base = MFMA(load_frag(mf, F_GMEAN + 1, lane), (acc_frag<1, false>(mean)), base);
-
-        // ---------------- pass 2: per-view global feature, softmax-weighted sum (online) ----------------
-        f32x16 agg;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) agg[i] = 0.f;
-        {
-            const f32x16 w_agg = load_tab(mf, TD_AGG, h);
-            const float b_agg = mf[TS_BAGG];
-            const half8 a_ga0 = load_frag(mf, F_GA, lane), a_ga1 = load_frag(mf, F_GA + 1, lane);
-            float mx = -INFINITY, den = 0.f;
-            for (int v = 0; v < V; ++v) {
-                float* st = stage + (size_t)v * STAGE_V;
-                const float* bl = st + STAGE_T;
-                half8 T1 = ((const half8*)st)[64 + lane];
-                f32x16 g = MFMA(a_view, T1, b_view);
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int ch = 8 * s + 4 * h + e;
-                        float fv = ch < GDB_CFR ? bl[(12 + ch) * 32 + j] : 0.f;
-                        g[4 * s + e] = fv + fmaxf(g[4 * s + e], 0.f);
-                    }
-#pragma unroll
-                for (int i = 12; i < 16; ++i) g[i] = 0.f;
-                f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
-                G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
-                float sp = dot16_relu(G, w_agg);
-                float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
-                float mn = fmaxf(mx, sv);
-                float sc_old = __expf(mx - mn), e = __expf(sv - mn);
-                den = den * sc_old + e;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
-                mx = mn;
-            }
-            float r = 1.f / den;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) agg[i] *= r;  // nerf.py:80
-        }
-        // ---------------- geometry branch ----------------
-        f32x16 im = load_tab(mf, TB_FC, h);  // nerf.py:82
-        im = MFMA(load_frag(mf, F_FC, lane), (acc_frag<0, false>(agg)), im);
-        im = MFMA(load_frag(mf, F_FC + 1, lane), (acc_frag<1, false>(agg)), im);
-        const half8 H0 = acc_frag<0, true>(im);  // im, ReLU'd
-        half8 H1;                                // vox channels 4h..4h+3
-#pragma unroll
-        for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
-        f32x16 x0 = load_tab(mf, TB_LR0, h), x1 = load_tab(mf, TB_LR0 + 32, h);  // nerf.py:100-101
-        x0 = MFMA(load_frag(mf, F_LR0, lane), H0, x0);
-        x0 = MFMA(load_frag(mf, F_LR0 + 1, lane), H1, x0);
-        x1 = MFMA(load_frag(mf, F_LR0 + 2, lane), H0, x1);
-        x1 = MFMA(load_frag(mf, F_LR0 + 3, lane), H1, x1);
-        const half8 X00 = acc_frag<0, true>(x0), X01 = acc_frag<1, true>(x0);
-        const half8 X10 = acc_frag<0, true>(x1), X11 = acc_frag<1, true>(x1);
-        f32x16 fh = load_tab(mf, TB_FH, h);  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        fh = MFMA(load_frag(mf, F_FH, lane), X00, fh);
-        fh = MFMA(load_frag(mf, F_FH + 1, lane), X01, fh);
-        fh = MFMA(load_frag(mf, F_FH + 2, lane), X10, fh);
-        fh = MFMA(load_frag(mf, F_FH + 3, lane), X11, fh);
-        // ---------------- colour branch: shared part of weight.0 ----------------
-        f32x16 hs0 = load_tab(mf, TB_W0, h), hs1 = load_tab(mf, TB_W0 + 32, h);
-        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane), X00, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0A + 1, lane), X01, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0A + 2, lane), X10, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0A + 3, lane), X11, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0B + 0, lane), H0, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0B + 1, lane), H1, hs0);
-        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane), X00, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0A + 5, lane), X01, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0A + 6, lane), X10, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0A + 7, lane), X11, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0B + 2, lane), H0, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0B + 3, lane), H1, hs1);
-
-        // ---------------- pass 3: per-view blend weight, softmax-weighted blend (online) ----------------
-        float bacc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-        {
-            const f32x16 w20 = load_tab(mf, TD_W2, h), w21 = load_tab(mf, TD_W2 + 32, h);
-            const float b_w2 = mf[TS_BW2];
-            const half8 c00 = load_frag(mf, F_W0C + 0, lane), c01 = load_frag(mf, F_W0C + 1, lane);
-            const half8 c10 = load_frag(mf, F_W0C + 2, lane), c11 = load_frag(mf, F_W0C + 3, lane);
-            float mx = -INFINITY, den = 0.f;
-            for (int v = 0; v < V; ++v) {
-                float* st = stage + (size_t)v * STAGE_V;
-                const float* bl = st + STAGE_T;
-                half8 T0 = ((const half8*)st)[lane], T1 = ((const half8*)st)[64 + lane];
-                f32x16 hv0 = MFMA(c00, T0, hs0);
-                hv0 = MFMA(c01, T1, hv0);
-                f32x16 hv1 = MFMA(c10, T0, hs1);
-                hv1 = MFMA(c11, T1, hv1);
-                float up = dot16_relu(hv0, w20) + dot16_relu(hv1, w21);
-                float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
-                float mn = fmaxf(mx, uv);
-                float sc_old = __expf(mx - mn), e = __expf(uv - mn);
-                den = den * sc_old + e;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int c = 16 * h + i;
-                    float val = c < NBLEND ? bl[c * 32 + j] : 0.f;
-                    bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
-                }
-                mx = mn;
-            }
-            float r = 1.f / den;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bacc[i] *= r;
-        }
-        // ---------------- hand this slot to the composite ----------------
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int c = 16 * h + i;
-            if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fmaxf(fh[i], 0.f) : 0.f;
-        if (h == 0) {
-            float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
-            ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
-            float sg = softplus_t20(fh[4]);
-            alpha_s[k * 32 + j] = act ? 1.f - __expf(-sg) : 0.f;  // utils.py:34
-        }
+    // [COMP_CH][COMP_LD] values, then alpha[32], wn[32] per slot
+    if (LOOP) {
+        for (int k = wid; k < S; k += nw)
+            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h);
+    } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
+        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h);
     }
     __syncthreads();
     // transmittance weights per bundle, normalised   utils.py:35-41
     if (threadIdx.x < 32) {
         float T = 1.f, sum = 0.f;
         for (int k = 0; k < S; ++k) {
-            float al = alpha_s[k * 32 + threadIdx.x];
+            float* rk = rec0 + (size_t)k * rec_stride;
+            float al = rk[COMP_ALPHA + threadIdx.x];
             float w = al * T;
             T = T * (1.f - al);
-            wn_s[k * 32 + threadIdx.x] = w;
+            rk[COMP_WN + threadIdx.x] = w;
             sum += w;
         }
         float den = fmaxf(sum, 1e-6f);
-        for (int k = 0; k < S; ++k) wn_s[k * 32 + threadIdx.x] = wn_s[k * 32 + threadIdx.x] / den;
+        for (int k = 0; k < S; ++k) {
+            float* rk = rec0 + (size_t)k * rec_stride;
+            rk[COMP_WN + threadIdx.x] = rk[COMP_WN + threadIdx.x] / den;
+        }
     }
     __syncthreads();
     // weighted sums; the segment's (N_b, 39) rows are one contiguous run in memory   utils.py:109-119
@@ -553,7 +620,10 @@ __global__ void __launch_bounds__(256) k_render_fused(FusedArgs a) {
     for (int qi = threadIdx.x; qi < nvalid * NOUT; qi += blockDim.x) {
         int jj = qi / NOUT, c = qi - jj * NOUT;
         float acc = 0.f;
-        for (int k = 0; k < S; ++k) acc += comp[(size_t)k * COMP_STRIDE + c * COMP_LD + jj] * wn_s[k * 32 + jj];
+        for (int k = 0; k < S; ++k) {
+            const float* rk = rec0 + (size_t)k * rec_stride;
+            acc += rk[c * COMP_LD + jj] * rk[COMP_WN + jj];
+        }
         a.bf[b0 * NOUT + qi] = acc;
     }
     if (threadIdx.x < 64) {
@@ -561,8 +631,9 @@ __global__ void __launch_bounds__(256) k_render_fused(FusedArgs a) {
         if (jj < nvalid) {
             float acc = 0.f;
             for (int k = 0; k < S; ++k) {
-                float w = wn_s[k * 32 + jj];
-                acc += which ? w : comp[(size_t)k * COMP_STRIDE + NOUT * COMP_LD + jj] * w;
+                const float* rk = rec0 + (size_t)k * rec_stride;
+                float w = rk[COMP_WN + jj];
+                acc += which ? w : rk[NOUT * COMP_LD + jj] * w;
             }
             if (which) a.opac[b0 + jj] = acc;
             else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
@@ -591,22 +662,25 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.nblk = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac;
     const int S = cfg->max_num_samples, V = fr->V;
-    const size_t fixed = sizeof(float) * ((size_t)S * COMP_STRIDE + 2 * (size_t)S * 32);
     const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
     const size_t lds_max = 160 * 1024;
     // at most 4 waves per workgroup (one per SIMD); with more slots than waves each wave loops
     int nw = S <= 4 ? S : (S + (S + 3) / 4 - 1) / ((S + 3) / 4);
-    while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
+    a.alias = (nw == S && per_wave >= sizeof(float) * COMP_REC) ? 1 : 0;
+    size_t fixed = a.alias ? 0 : sizeof(float) * (size_t)S * COMP_REC;
+    while (nw > 1 && fixed + nw * per_wave > lds_max) { --nw; a.alias = 0; fixed = sizeof(float) * (size_t)S * COMP_REC; }
     size_t lds = fixed + nw * per_wave;
     if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = lds_max;
     }
     unsigned grid = (unsigned)((a.nblk + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_render_fused, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    if (nw == S) hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
     return GDB_OK;
