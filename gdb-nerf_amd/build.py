@@ -9,8 +9,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdbnerf_hip.so")
 SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip")
-# -ffp-contract=off: a*b+c stays two roundings (as separate torch ops are) unless written fmaf().
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 mul/add into v_pk_*_f32 with op_sel
+# modifiers; in the fused kernel that produced stale values in lanes 48..63 of one packed result
+# whenever two or more workgroups shared a CU (run-to-run different bundles, found with
+# tools/dbg_fused.py; gone with one workgroup per CU or without packing).  Packed f32 math is no
+# faster beside MFMA (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), so it is off.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
+# the fused fast path lets the compiler contract.
+CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast"}
 
 
 def _stale() -> bool:
@@ -29,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -21,8 +21,8 @@
 //                weighted sum run per bundle; the (N_b, 39) output rows are written as one
 //                contiguous run per segment.
 #include "gdb_internal.h"
+#include <cstdlib>
 #include <cstring>
-#include <vector>
 
 int gdb_fail(int code, const char* fmt, ...);
 int gdb_check_cfg(const GdbConfig* c);
@@ -158,13 +158,22 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 // ---- device side ----------------------------------------------------------------------------
 // Compiler-only fence: weight fragments are loop-invariant global loads, and without it hipcc
 // hoists all 33 of them (132 VGPRs) to kernel entry.
+#ifdef GDB_DEBUG_VOLATILE_LDS
+#define BLVOL volatile
+#else
+#define BLVOL
+#endif
 #define PHASE_FENCE() asm volatile("" ::: "memory")
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
 constexpr int STAGE_T = 512;                 // floats: two tail fragments of one view (2 x 1 KiB)
+#ifdef GDB_DEBUG_CHECK
+constexpr int STAGE_B = 32 * 32;             // debug: a spare row 31 holds a second copy of row 7
+#else
 constexpr int STAGE_B = NBLEND * 32;         // floats: blend values [31][32]
+#endif
 constexpr int STAGE_V = STAGE_T + STAGE_B;   // per (wave, view)
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite staging
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
@@ -175,9 +184,12 @@ constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot 
 struct FusedArgs {
     DevFrame f;
     const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nblk, alias;
+    int row_begin, nrows, nseg, nblk, alias, lds_floats;
     float* bf; float* depth; float* opac;
+    unsigned* dbg;
 };
+static unsigned* g_dbg = nullptr;
+extern "C" void gdb_debug_set_buffer(void* p) { g_dbg = (unsigned*)p; }
 
 __device__ __forceinline__ float to_h_range(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 
@@ -188,8 +200,7 @@ __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float v = a[8 * S + i];
-        if (RELU) v = fmaxf(v, 0.f);
-        r[i] = (_Float16)to_h_range(v);
+        r[i] = (_Float16)(RELU ? __builtin_amdgcn_fmed3f(v, 0.f, 65504.f) : to_h_range(v));
     }
     return r;
 }
@@ -212,28 +223,67 @@ __device__ __forceinline__ float dot16_relu(const f32x16& a, const f32x16& w) {
     return s;
 }
 
-// One mip level, this lane's 16-B chunks only (chunk c = 2*slot + h, slot 0..2).
-__device__ __forceinline__ void tex_level_part(const DevFrame& f, const float* __restrict__ pyr, int l, float u, float v, int h,
-                                               float4 out[3]) {
-    int W = f.lvlW[l], H = f.lvlH[l];
+// ---- fast-path arithmetic (this translation unit is built with -ffp-contract=fast) ------------
+// The fused kernel trades the last ulp of the geometry for VALU issue slots: reciprocal-based
+// division, v_rsq / v_sqrt / v_log, fused multiply-adds.  The one discrete decision of the path,
+// the per-bundle sample count (bundle_sampler.py:179), keeps its IEEE division (sample_count()).
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// F.normalize(p=2, eps=1e-12): x / max(|x|, 1e-12)
+__device__ __forceinline__ void fnormalize3(const float a[3], float o[3]) {
+    float r = frsq(fmaxf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2], 1e-24f));
+    o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
+}
+
+// Bilinear taps of one mip level in float4 units of the channel-last pyramid (texel = 5 float4):
+// tap indices (without the chunk) and weights, clamp-to-edge.  lw scales the level's weights.
+struct Taps { unsigned i00, i10, i01, i11; float w00, w10, w01, w11; };
+__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsigned lvl4, float lw) {
     int x0, x1, y0, y1; float fx, fy;
     tex_coord(u, W, x0, x1, fx);
     tex_coord(v, H, y0, y1, fy);
-    const float* base = pyr + f.lvlOff[l];
-    const float4* a00 = (const float4*)(base + ((size_t)y0 * W + x0) * GDB_CP);
-    const float4* a10 = (const float4*)(base + ((size_t)y0 * W + x1) * GDB_CP);
-    const float4* a01 = (const float4*)(base + ((size_t)y1 * W + x0) * GDB_CP);
-    const float4* a11 = (const float4*)(base + ((size_t)y1 * W + x1) * GDB_CP);
+    Taps t;
+    unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
+    t.i00 = lvl4 + (r0 + x0) * 5u; t.i10 = lvl4 + (r0 + x1) * 5u;
+    t.i01 = lvl4 + (r1 + x0) * 5u; t.i11 = lvl4 + (r1 + x1) * 5u;
+    float ex = (1.f - fx) * lw, wx = fx * lw;
+    t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
+    return t;
+}
+__device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
+    o.x = fmaf(a.x, w, o.x); o.y = fmaf(a.y, w, o.y); o.z = fmaf(a.z, w, o.z); o.w = fmaf(a.w, w, o.w);
+}
+__device__ __forceinline__ void taps_fetch(const float4* __restrict__ p, const Taps& t, int h, float4 acc[3]) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        int c = 2 * s + h;
+        unsigned c = 2 * s + h;
         if (c < GDB_CP / 4) {
-            float4 top = lerp4(a00[c], a10[c], fx);
-            float4 bot = lerp4(a01[c], a11[c], fx);
-            out[s] = lerp4(top, bot, fy);
-        } else {
-            out[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tap_acc(acc[s], p[t.i00 + c], t.w00);
+            tap_acc(acc[s], p[t.i10 + c], t.w10);
+            tap_acc(acc[s], p[t.i01 + c], t.w01);
+            tap_acc(acc[s], p[t.i11 + c], t.w11);
         }
+    }
+}
+
+// Bilinear RGB, grid_sample border / align_corners=False, from planar (3,Ho,Wo); 32-bit offsets.
+__device__ __forceinline__ void rgb_fetch_fast(const float* __restrict__ img, int Ho, int Wo, float px, float py, float rgb[3]) {
+    // px, py are pixel coordinates (x*Wo/Wo form folded): grid g = 2*px/Wo - 1 -> ((g+1)*Wo - 1)/2 = px - 0.5
+    float x = fminf(fmaxf(px - 0.5f, 0.f), (float)(Wo - 1)), y = fminf(fmaxf(py - 0.5f, 0.f), (float)(Ho - 1));
+    float xf = floorf(x), yf = floorf(y);
+    float wx = x - xf, wy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf;
+    int x1 = min(x0 + 1, Wo - 1), y1 = min(y0 + 1, Ho - 1);  // a clamped tap carries weight 0 (wx = 0 at the edge)
+    float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
+    unsigned o00 = (unsigned)(y0 * Wo + x0), o10 = (unsigned)(y0 * Wo + x1), o01 = (unsigned)(y1 * Wo + x0), o11 = (unsigned)(y1 * Wo + x1);
+    unsigned plane = (unsigned)(Ho * Wo);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = img + c * plane;
+        rgb[c] = fmaf(p[o11], w11, fmaf(p[o01], w01, fmaf(p[o10], w10, p[o00] * w00)));
     }
 }
 
@@ -260,67 +310,74 @@ __device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const hal
 
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
-__device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[4][3], const float ctr[3],
+__device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float* __restrict__ tc, f32x16& tv, float rgb[2][3]) {
     const float* sc = src_cam(f, bi, v);
-    float cc[3] = {0.f, 0.f, 0.f};
-    float cam[4][3];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            cam[s][r] = sc[S_E + 4 * r] * xyz[s][0] + sc[S_E + 4 * r + 1] * xyz[s][1] + sc[S_E + 4 * r + 2] * xyz[s][2] + sc[S_E + 4 * r + 3];
-            cc[r] += cam[s][r];
-        }
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :332-337
-        const float* cm = h ? cam[2 + e] : cam[e];
-        float im[3];
+    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
+        float cm[3], im[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cm[0] + sc[S_K + 3 * r + 1] * cm[1] + sc[S_K + 3 * r + 2] * cm[2];
-        float zc = fmaxf(im[2], 1e-6f);
-        rgb_fetch(img, f.Ho, f.Wo, 2.f * (im[0] / zc) / (float)f.Wo - 1.f, 2.f * (im[1] / zc) / (float)f.Ho - 1.f, rgb[e]);
+        for (int r = 0; r < 3; ++r)
+            cm[r] = fmaf(sc[S_E + 4 * r], xyz[e][0], fmaf(sc[S_E + 4 * r + 1], xyz[e][1], fmaf(sc[S_E + 4 * r + 2], xyz[e][2], sc[S_E + 4 * r + 3])));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) im[r] = fmaf(sc[S_K + 3 * r], cm[0], fmaf(sc[S_K + 3 * r + 1], cm[1], sc[S_K + 3 * r + 2] * cm[2]));
+        float iz = frcp(fmaxf(im[2], 1e-6f));
+        rgb_fetch_fast(img, f.Ho, f.Wo, im[0] * iz, im[1] * iz, rgb[e]);
     }
+    // sphere centre in the camera frame: the mean of the sub-ray points maps to the mean of their images   :340
+    float cc[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) cc[r] = cc[r] / 4.f;
-    float level = mip_level(cc[0], cc[1], cc[2], ball, sc[S_PIXR]);  // :343-348
+    for (int r = 0; r < 3; ++r)
+        cc[r] = fmaf(sc[S_E + 4 * r], ctr[0], fmaf(sc[S_E + 4 * r + 1], ctr[1], fmaf(sc[S_E + 4 * r + 2], ctr[2], sc[S_E + 4 * r + 3])));
+    // footprint -> mip level   :343-348
+    float d2 = cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2];
+    float icz = frcp(cc[2]), ib = frcp(ball);
+    float sec2 = d2 * icz * icz;
+    float aa = fsqrt(fmaxf(d2 * ib * ib - 1.f, 1e-12f)), cq = fsqrt(fmaxf(sec2 - 1.f, 1e-12f));
+    float level = __builtin_amdgcn_logf(sec2 * frcp(aa + cq) * frcp(sc[S_PIXR]));  // v_log_f32 = log2
     float ci[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) ci[r] = sc[S_KS + 3 * r] * cc[0] + sc[S_KS + 3 * r + 1] * cc[1] + sc[S_KS + 3 * r + 2] * cc[2];
-    float zc = fmaxf(ci[2], 1e-6f);
-    float tu = ci[0] / zc / (float)f.W, tvv = ci[1] / zc / (float)f.H;
-    const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
+    for (int r = 0; r < 3; ++r) ci[r] = fmaf(sc[S_KS + 3 * r], cc[0], fmaf(sc[S_KS + 3 * r + 1], cc[1], sc[S_KS + 3 * r + 2] * cc[2]));
+    float iz = frcp(fmaxf(ci[2], 1e-6f));
+    float tu = ci[0] * iz * frcp((float)f.W), tvv = ci[1] * iz * frcp((float)f.H);   // :351-353
+    // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
-    float4 t0[3];
-    tex_level_part(f, pyr, l0, tu, tvv, h, t0);
-    if (frac > 0.f) {
-        float4 t1[3];
-        tex_level_part(f, pyr, l1, tu, tvv, h, t1);
+    const float4* pyr = (const float4*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
+    float4 acc[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) t0[s] = lerp4(t0[s], t1[s], frac);
+    for (int s = 0; s < 3; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : (l0 == 3 ? f.lvlOff[3] : f.lvlOff[4])));
+        Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
+        taps_fetch(pyr, t, h, acc);
+    }
+    if (frac > 0.f) {
+        unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : (l1 == 3 ? f.lvlOff[3] : f.lvlOff[4]));
+        Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
+        taps_fetch(pyr, t, h, acc);
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) { tv[4 * s] = t0[s].x; tv[4 * s + 1] = t0[s].y; tv[4 * s + 2] = t0[s].z; tv[4 * s + 3] = t0[s].w; }
+    for (int s = 0; s < 3; ++s) { tv[4 * s] = acc[s].x; tv[4 * s + 1] = acc[s].y; tv[4 * s + 2] = acc[s].z; tv[4 * s + 3] = acc[s].w; }
     // view-direction code   :362-367
     float td[3], sd[3], dd[3], dif[3], dnn[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - tc[T_O + r];
-    normalize3(dd, td);
+    fnormalize3(dd, td);
 #pragma unroll
     for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - sc[S_C + r];
-    normalize3(dd, sd);
+    fnormalize3(dd, sd);
 #pragma unroll
     for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
-    normalize3(dif, dnn);
+    fnormalize3(dif, dnn);
     if (h == 0) { tv[12] = dnn[0]; tv[13] = dnn[1]; tv[14] = dnn[2]; tv[15] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2]; }
 }
 
 // One sample slot k of the workgroup's 32 bundles: gather, MLP, record for the composite.
-__device__ __forceinline__ void render_slot(const DevFrame& f, const float* __restrict__ mf, float* __restrict__ stage,
-                                            float* __restrict__ ck, const float* __restrict__ tc, int k, int bi, int row,
-                                            int x, bool inrow, int lane, int j, int h) {
+__device__ __forceinline__ void render_slot(const DevFrame& f, const float* __restrict__ mf, float* stage,
+                                            float* ck, const float* __restrict__ tc, int k, int bi, int row,
+                                            int x, bool inrow, int lane, int j, int h, unsigned* dbg) {
     const int V = f.V;
     {
         float z;
@@ -345,27 +402,32 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
                 float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
                 float wx = gx - xf, wy = gy - yf, wz = gz - zf;
                 int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
-                const size_t plane = (size_t)f.H * f.W, cs = plane * f.D;
-                const float* vol = f.feat_volume + ((size_t)bi * GDB_CV + 4 * h) * cs;
+                const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
+                const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
+                const unsigned cb = 4u * (unsigned)h * cs;
 #pragma unroll
                 for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx) {
-                            int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-                            bool in = xx <= f.W - 1 && yy <= f.H - 1 && zz <= f.D - 1;
+                            int xx = min(x0 + dx, f.W - 1), yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
+                            // a tap clamped at the far edge carries weight 0 (its fraction is 0 there)
                             float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                            if (!in) wgt = 0.f;
-                            size_t off = ((size_t)min(zz, f.D - 1) * f.H + min(yy, f.H - 1)) * f.W + min(xx, f.W - 1);
+                            unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xx);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) vox[c] += vol[c * cs + off] * wgt;
+                            for (int c = 0; c < 4; ++c) vox[c] = fmaf(vol[off + c * cs], wgt, vox[c]);
                         }
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+            float xyzh[2][3];  // this half's two sub-ray points
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
 
             for (int v = 0; v < V; ++v) {
                 float* st = stage + (size_t)v * STAGE_V;
@@ -373,8 +435,8 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
 #pragma unroll
                 for (int i = 0; i < 16; ++i) tv[i] = 0.f;
                 float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-                if (act) gather_view(f, bi, v, h, xyz, ctr, ball, tc, tv, rgb);
-                float* bl = st + STAGE_T;
+                if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, tv, rgb);
+                BLVOL float* bl = st + STAGE_T;
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -388,6 +450,14 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
                     }
                 ((half8*)st)[lane] = acc_frag<0, false>(tv);
                 ((half8*)st)[64 + lane] = acc_frag<1, false>(tv);
+#ifdef GDB_DEBUG_CHECK
+                if (h == 1) bl[31 * 32 + j] = rgb[1][1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (h == 1 && dbg) {
+                    float rb = ((volatile float*)bl)[7 * 32 + j];
+                    if (__float_as_uint(rb) != __float_as_uint(rgb[1][1])) atomicAdd(dbg + 0, 1u);
+                }
+#endif
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -535,6 +605,12 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
                     bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
                 }
                 mx = mn;
+#ifdef GDB_DEBUG_CHECK
+                if (h == 0 && dbg) {
+                    float r7 = ((volatile const float*)bl)[7 * 32 + j], r31 = ((volatile const float*)bl)[31 * 32 + j];
+                    if (__float_as_uint(r7) != __float_as_uint(r31)) atomicAdd(dbg + 1, 1u);
+                }
+#endif
                 PHASE_FENCE();
             }
             float r = 1.f / den;
@@ -556,6 +632,14 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
             ck[COMP_ALPHA + j] = act ? 1.f - __expf(-softplus_t20(sig)) : 0.f;  // utils.py:34
         }
+#ifdef GDB_DEBUG_CHECK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h == 0 && dbg) {
+            float rb = ((volatile float*)ck)[7 * COMP_LD + j];
+            float want = act ? bacc[7] : 0.f;
+            if (__float_as_uint(rb) != __float_as_uint(want)) atomicAdd(dbg + 2, 1u);
+        }
+#endif
         }
 }
 
@@ -591,9 +675,9 @@ __global__ void __launch_bounds__(256, 3) k_render_fused(FusedArgs a) {
     // [COMP_CH][COMP_LD] values, then alpha[32], wn[32] per slot
     if (LOOP) {
         for (int k = wid; k < S; k += nw)
-            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h);
+            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h, a.dbg);
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
-        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h);
+        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h, a.dbg);
     }
     __syncthreads();
     // transmittance weights per bundle, normalised   utils.py:35-41
@@ -660,17 +744,19 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.row_begin = row_begin; a.nrows = row_end - row_begin;
     a.nseg = (fr->W + 31) / 32;
     a.nblk = fr->B * a.nrows * a.nseg;
-    a.bf = bf; a.depth = depth; a.opac = opac;
+    a.bf = bf; a.depth = depth; a.opac = opac; a.dbg = g_dbg;
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
     const size_t lds_max = 160 * 1024;
     // at most 4 waves per workgroup (one per SIMD); with more slots than waves each wave loops
     int nw = S <= 4 ? S : (S + (S + 3) / 4 - 1) / ((S + 3) / 4);
-    a.alias = (nw == S && per_wave >= sizeof(float) * COMP_REC) ? 1 : 0;
+    a.alias = (nw == S && per_wave >= sizeof(float) * COMP_REC && !getenv("GDB_FUSED_NO_ALIAS")) ? 1 : 0;
     size_t fixed = a.alias ? 0 : sizeof(float) * (size_t)S * COMP_REC;
     while (nw > 1 && fixed + nw * per_wave > lds_max) { --nw; a.alias = 0; fixed = sizeof(float) * (size_t)S * COMP_REC; }
     size_t lds = fixed + nw * per_wave;
+    if (getenv("GDB_FUSED_BIG_LDS")) lds = lds_max > lds ? (size_t)atoi(getenv("GDB_FUSED_BIG_LDS")) : lds;
     if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
+    a.lds_floats = (int)(lds / 4);
     static size_t attr_set = 0;
     if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);

@@ -249,6 +249,18 @@ def test_fused_matches_unfused_at_full_size():
     assert _psnr_delta(npy(bf), npy(ubf), 256, 320) <= 0.05
 
 
+def test_fused_is_deterministic_at_full_size():
+    """Regression for a race seen only with several workgroups per CU at full frame size (stale lanes in a
+    packed-f32 result): repeated launches must agree bit for bit, and with the fp32 operator chain."""
+    frame = synthetic.make_frame(512, 640, V=3, seed=3)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=2), max_num_samples=3, is_adaptive=True)
+    ref = eng.render()[0].clone()
+    ubf = eng.render_unfused()[0]
+    for _ in range(6):
+        assert torch.equal(eng.render()[0], ref)
+    assert max_abs(npy(ref), npy(ubf)) <= FUSED_TOL
+
+
 def test_fused_row_strips_tile_the_frame():
     """Row-strip launches (the multi-GPU shard unit) reproduce the full-frame launch bit for bit."""
     frame = synthetic.make_frame(64, 80, V=3, B=2, seed=4)
