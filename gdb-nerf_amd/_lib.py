@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgdbnerf_hip.so")
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
-GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 4, 8
+GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8
 
 
 class GdbConfig(C.Structure):

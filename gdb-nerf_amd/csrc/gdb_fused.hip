@@ -349,12 +349,12 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 #pragma unroll
     for (int s = 0; s < 3; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : (l0 == 3 ? f.lvlOff[3] : f.lvlOff[4])));
+        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : f.lvlOff[3]));
         Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
         taps_fetch(pyr, t, h, acc);
     }
     if (frac > 0.f) {
-        unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : (l1 == 3 ? f.lvlOff[3] : f.lvlOff[4]));
+        unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : f.lvlOff[3]);
         Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
         taps_fetch(pyr, t, h, acc);
     }

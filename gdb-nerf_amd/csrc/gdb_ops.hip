@@ -103,11 +103,10 @@ __device__ void invert_f64(const double* a, double* out) {  // Gauss-Jordan, par
     for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) out[i * N + j] = m[i][N + N * 0 + j];
 }
 
-__global__ void k_cam_prep(int B, int V, int b, int inv_depth, int gnd, const float* __restrict__ tar_exts,
+__device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd, const float* __restrict__ tar_exts,
                            const float* __restrict__ tar_ints, const float* __restrict__ src_exts,
                            const float* __restrict__ src_ints, const float* __restrict__ near_far,
                            float* __restrict__ cams) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
     int per = V + 1;
     if (t >= B * per) return;
     int bi = t / per, v = t % per - 1;
@@ -152,45 +151,68 @@ __global__ void k_cam_prep(int B, int V, int b, int inv_depth, int gnd, const fl
 // ============================================================================================
 // feature pyramid: NCHW (B*V, C_f+3, H, W) -> channel-last, 20-float texels, + box mips
 // ============================================================================================
-// Level 0: one thread per (texel, 4-channel chunk).  Consecutive lanes walk x, so each of the
-// four channel-plane reads is a coalesced 256-B row segment; the write is one 16-B chunk.
-__global__ void k_pyr_level0(int BV, int C, int H, int W, unsigned pyrStride, const float* __restrict__ src,
-                             float* __restrict__ pyr) {
-    size_t n = (size_t)BV * (GDB_CP / 4) * H * W;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    int x = (int)(t % W); size_t r = t / W;
-    int y = (int)(r % H); r /= H;
-    int chunk = (int)(r % (GDB_CP / 4)); int bv = (int)(r / (GDB_CP / 4));
-    const float* s = src + (size_t)bv * C * H * W + (size_t)y * W + x;
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = chunk * 4 + i;
-        v[i] = c < C ? s[(size_t)c * H * W] : 0.f;
-    }
-    float4* dst = (float4*)(pyr + (size_t)bv * pyrStride + ((size_t)y * W + x) * GDB_CP + chunk * 4);
-    *dst = make_float4(v[0], v[1], v[2], v[3]);
-}
+// One launch for the whole per-frame preparation.  Workgroups 0..ntiles-1 each take a 32x8 tile of
+// one (batch, view) feature map: read NCHW along x (128-B row segments), keep the tile channel-last
+// in LDS, write level 0 as whole 640-float texel rows and box-filter levels 1..3 (16x4, 8x2, 4x1
+// texels) out of LDS.  The last workgroup computes the camera block.
+#define PT_W 32
+#define PT_H 8
+struct PrepArgs {
+    int B, V, H, W, levels, tilesX, tilesY, ntiles, b, inv_depth, gnd;
+    int lvlH[GDB_MAX_MIP + 1], lvlW[GDB_MAX_MIP + 1];
+    unsigned lvlOff[GDB_MAX_MIP + 1];
+    unsigned pyrStride;
+    const float* img_feat; float* pyr;
+    const float* tar_exts; const float* tar_ints; const float* src_exts; const float* src_ints; const float* near_far;
+    float* cams;
+};
 
-// Level l from level l-1: 2x2 box average, (a+b+c+d)*0.25, one thread per (texel, chunk).
-__global__ void k_pyr_down(int BV, int Hs, int Ws, unsigned pyrStride, unsigned offSrc, unsigned offDst,
-                           float* __restrict__ pyr) {
-    int Hd = Hs / 2, Wd = Ws / 2;
-    size_t n = (size_t)BV * Hd * Wd * (GDB_CP / 4);
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    int chunk = (int)(t % (GDB_CP / 4)); size_t r = t / (GDB_CP / 4);
-    int x = (int)(r % Wd); r /= Wd;
-    int y = (int)(r % Hd); int bv = (int)(r / Hd);
-    const float* base = pyr + (size_t)bv * pyrStride + offSrc;
-    const float4 a = *(const float4*)(base + ((size_t)(2 * y) * Ws + 2 * x) * GDB_CP + chunk * 4);
-    const float4 b = *(const float4*)(base + ((size_t)(2 * y) * Ws + 2 * x + 1) * GDB_CP + chunk * 4);
-    const float4 c = *(const float4*)(base + ((size_t)(2 * y + 1) * Ws + 2 * x) * GDB_CP + chunk * 4);
-    const float4 d = *(const float4*)(base + ((size_t)(2 * y + 1) * Ws + 2 * x + 1) * GDB_CP + chunk * 4);
-    float4 o = make_float4((a.x + b.x + c.x + d.x) * 0.25f, (a.y + b.y + c.y + d.y) * 0.25f,
-                           (a.z + b.z + c.z + d.z) * 0.25f, (a.w + b.w + c.w + d.w) * 0.25f);
-    *(float4*)(pyr + (size_t)bv * pyrStride + offDst + ((size_t)y * Wd + x) * GDB_CP + chunk * 4) = o;
+__global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
+    __shared__ float4 tile4[(PT_W * PT_H + 16 * 4 + 8 * 2 + 4) * (GDB_CP / 4)];
+    if ((int)blockIdx.x >= a.ntiles) {
+        for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
+            cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
+        return;
+    }
+    float* tile = (float*)tile4;
+    const int tx = blockIdx.x % a.tilesX, ty = (blockIdx.x / a.tilesX) % a.tilesY, bv = blockIdx.x / (a.tilesX * a.tilesY);
+    const int x0 = tx * PT_W, y0 = ty * PT_H;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool in0 = gx < a.W && gy < a.H;
+    const float* src = a.img_feat + (size_t)bv * GDB_CFR * a.H * a.W + (size_t)min(gy, a.H - 1) * a.W + min(gx, a.W - 1);
+    float* t0 = tile + (size_t)threadIdx.x * GDB_CP;
+#pragma unroll
+    for (int c = 0; c < GDB_CFR; ++c) t0[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
+    t0[GDB_CFR] = 0.f;
+    __syncthreads();
+    float* pyr = a.pyr + (size_t)bv * a.pyrStride;
+    // level 0: each tile row is 32 texels x 5 float4, contiguous in the channel-last layout
+    for (int i = threadIdx.x; i < PT_W * PT_H * (GDB_CP / 4); i += blockDim.x) {
+        int r = i / (PT_W * (GDB_CP / 4)), q = i - r * (PT_W * (GDB_CP / 4));  // q: float4 index inside the row
+        int px = x0 + q / (GDB_CP / 4), py = y0 + r;
+        if (px < a.W && py < a.H) ((float4*)(pyr + ((size_t)py * a.W + x0) * GDB_CP))[q] = tile4[i];
+    }
+    // levels 1..3 from the level below, in LDS; (a+b+c+d)*0.25 as nvdiffrast's mip construction
+    int srcBase = 0, sw = PT_W, sh = PT_H;
+    for (int l = 1; l <= a.levels; ++l) {
+        const int dw = sw >> 1, dh = sh >> 1, dstBase = srcBase + sw * sh;
+        const int W_l = a.lvlW[l], H_l = a.lvlH[l];
+        for (int i = threadIdx.x; i < dw * dh * (GDB_CP / 4); i += blockDim.x) {
+            int ch = i % (GDB_CP / 4), p = i / (GDB_CP / 4), dx = p % dw, dy = p / dw;
+            const float4 A = tile4[(srcBase + (2 * dy) * sw + 2 * dx) * (GDB_CP / 4) + ch];
+            const float4 Bq = tile4[(srcBase + (2 * dy) * sw + 2 * dx + 1) * (GDB_CP / 4) + ch];
+            const float4 C = tile4[(srcBase + (2 * dy + 1) * sw + 2 * dx) * (GDB_CP / 4) + ch];
+            const float4 D = tile4[(srcBase + (2 * dy + 1) * sw + 2 * dx + 1) * (GDB_CP / 4) + ch];
+            float4 o = make_float4((A.x + Bq.x + C.x + D.x) * 0.25f, (A.y + Bq.y + C.y + D.y) * 0.25f,
+                                   (A.z + Bq.z + C.z + D.z) * 0.25f, (A.w + Bq.w + C.w + D.w) * 0.25f);
+            tile4[(dstBase + dy * dw + dx) * (GDB_CP / 4) + ch] = o;
+            int px = (x0 >> l) + dx, py = (y0 >> l) + dy;
+            if (px < W_l && py < H_l) ((float4*)(pyr + a.lvlOff[l] + ((size_t)py * W_l + px) * GDB_CP))[ch] = o;
+        }
+        __syncthreads();
+        srcBase = dstBase; sw = dw; sh = dh;
+    }
 }
 
 extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
@@ -200,23 +222,19 @@ extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, si
     WsLayout L = ws_layout(*cfg, *f);
     if (ws_bytes < L.total) return gdb_fail(GDB_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
     hipStream_t st = (hipStream_t)stream_;
-    float* cams = (float*)((char*)ws + L.camsOff);
-    float* pyr = (float*)((char*)ws + L.pyrOff);
-    int ncam = f->B * (f->V + 1);
-    hipLaunchKernelGGL(k_cam_prep, dim3((ncam + 63) / 64), dim3(64), 0, st, f->B, f->V, cfg->bundle_size, cfg->inv_depth,
-                       cfg->global_num_depth, f->d_tar_exts, f->d_tar_ints, f->d_src_exts, f->d_src_ints, f->d_near_far, cams);
-    LAUNCH_CHECK("k_cam_prep");
-    int BV = f->B * f->V;
-    size_t n0 = (size_t)BV * (GDB_CP / 4) * f->H * f->W;
-    hipLaunchKernelGGL(k_pyr_level0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, BV, GDB_CFR, f->H, f->W,
-                       (unsigned)L.pyrStride, f->d_img_feat, pyr);
-    LAUNCH_CHECK("k_pyr_level0");
-    for (int l = 1; l <= L.levels; ++l) {
-        size_t n = (size_t)BV * L.lvlH[l] * L.lvlW[l] * (GDB_CP / 4);
-        hipLaunchKernelGGL(k_pyr_down, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, BV, L.lvlH[l - 1], L.lvlW[l - 1],
-                           (unsigned)L.pyrStride, (unsigned)L.lvlOff[l - 1], (unsigned)L.lvlOff[l], pyr);
-        LAUNCH_CHECK("k_pyr_down");
-    }
+    PrepArgs a{};
+    a.B = f->B; a.V = f->V; a.H = f->H; a.W = f->W; a.levels = L.levels;
+    if (a.levels > 3) return gdb_fail(GDB_E_BADARG, "max_mipmap_level > 3 unsupported by the tile kernel");
+    a.tilesX = (f->W + PT_W - 1) / PT_W; a.tilesY = (f->H + PT_H - 1) / PT_H;
+    a.ntiles = a.tilesX * a.tilesY * f->B * f->V;
+    a.b = cfg->bundle_size; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
+    for (int i = 0; i <= GDB_MAX_MIP; ++i) { a.lvlH[i] = L.lvlH[i]; a.lvlW[i] = L.lvlW[i]; a.lvlOff[i] = (unsigned)L.lvlOff[i]; }
+    a.pyrStride = (unsigned)L.pyrStride;
+    a.img_feat = f->d_img_feat; a.pyr = (float*)((char*)ws + L.pyrOff);
+    a.tar_exts = f->d_tar_exts; a.tar_ints = f->d_tar_ints; a.src_exts = f->d_src_exts; a.src_ints = f->d_src_ints;
+    a.near_far = f->d_near_far; a.cams = (float*)((char*)ws + L.camsOff);
+    hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_prepare");
     return GDB_OK;
 }
 

@@ -56,7 +56,7 @@ typedef struct GdbConfig {
 } GdbConfig;
 
 #define GDB_MAX_SAMPLES 16
-#define GDB_MAX_MIP 4
+#define GDB_MAX_MIP 3
 #define GDB_MAX_VIEWS 8
 
 /* One batch of hot-path inputs (Network.forward, network.py:114-166). */
