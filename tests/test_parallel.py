@@ -1,0 +1,62 @@
+"""Row-strip sharding of one frame over ranks and the all-gather of rendered strips
+(gdb-nerf_amd/parallel.py), exercised with world_size-2/3 gloo process groups on the CPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gdb_nerf_amd.parallel import all_strips, gather_strips, row_strip
+
+
+@pytest.mark.parametrize("H,world", [(256, 8), (256, 1), (10, 4), (3, 8), (37, 5), (1, 2)])
+def test_row_strips_partition_rows(H, world):
+    strips = all_strips(H, world)
+    assert strips[0][0] == 0 and strips[-1][1] == H
+    for (a0, a1), (b0, b1) in zip(strips, strips[1:]):
+        assert a1 == b0 and a0 <= a1
+    sizes = [b - a for a, b in strips]
+    assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+    with pytest.raises(ValueError):
+        row_strip(H, world, world)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, B, H, W, C, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(B * H * W * C, dtype=torch.float32).view(B * H * W, C)  # what a full render would hold
+        mine = torch.full_like(full, float("nan"))                                   # this rank renders only its strip
+        r0, r1 = row_strip(H, rank, world)
+        mine.view(B, H, W, C)[:, r0:r1] = full.view(B, H, W, C)[:, r0:r1]
+        out = gather_strips(mine, H, world, dist, B=B)
+        ok = bool(torch.equal(out, full))
+        depth = torch.full((B * H * W,), -1.0)
+        depth.view(B, H, W)[:, r0:r1] = full[:, 0].view(B, H, W)[:, r0:r1]
+        ok = ok and bool(torch.equal(gather_strips(depth, H, world, dist, B=B), full[:, 0].contiguous()))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,H,W,C", [(2, 1, 8, 5, 39), (2, 2, 7, 4, 3), (3, 1, 4, 6, 2)])
+def test_gather_strips_gloo(world, B, H, W, C):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, H, W, C, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
