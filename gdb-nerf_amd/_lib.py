@@ -46,6 +46,8 @@ _SIGNATURES = {
     "gdb_encode": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "gdb_mlp": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "gdb_composite": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "gdb_render_weights": (C.c_int, [_CFG, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "gdb_accumulate": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

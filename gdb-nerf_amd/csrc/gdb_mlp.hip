@@ -318,3 +318,38 @@ extern "C" int gdb_composite(const GdbConfig* cfg, const float* sigma, const flo
     LAUNCH_CHECK("k_comp_accum");
     return GDB_OK;
 }
+
+static int seg_bounds(const int64_t* idx, const int64_t* total, int64_t n_alloc, int64_t n_bundles, int32_t* seg, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(seg, 0, sizeof(int32_t) * 2 * (size_t)n_bundles, st);
+    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, st, idx, total, n_alloc, n_bundles, seg);
+    LAUNCH_CHECK("k_seg_bounds");
+    return GDB_OK;
+}
+
+extern "C" int gdb_render_weights(const GdbConfig* cfg, const float* sigma, const int64_t* idx, const int64_t* total,
+                                  int64_t n_alloc, int64_t n_bundles, float* weights, void* scratch, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    if (!sigma || !idx || !weights || !scratch) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (n_alloc < 1 || n_bundles < 1 || n_alloc >= ((int64_t)1 << 31)) return gdb_fail(GDB_E_SHAPE, "bad sizes");
+    hipStream_t st = (hipStream_t)stream_;
+    rc = seg_bounds(idx, total, n_alloc, n_bundles, (int32_t*)scratch, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_comp_weights, dim3((unsigned)((n_bundles + 255) / 256)), dim3(256), 0, st, n_bundles, (const int32_t*)scratch, sigma, weights);
+    LAUNCH_CHECK("k_comp_weights");
+    return GDB_OK;
+}
+
+extern "C" int gdb_accumulate(const GdbConfig* cfg, const float* weights, const float* feat, const float* z, const int64_t* idx,
+                              const int64_t* total, int64_t n_alloc, int64_t n_bundles, int32_t channels, float* fm, float* dm,
+                              float* om, void* scratch, void* stream_) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    if (!weights || !feat || !z || !idx || !fm || !dm || !om || !scratch) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (n_alloc < 1 || n_bundles < 1 || channels < 1 || n_alloc >= ((int64_t)1 << 31)) return gdb_fail(GDB_E_SHAPE, "bad sizes");
+    hipStream_t st = (hipStream_t)stream_;
+    rc = seg_bounds(idx, total, n_alloc, n_bundles, (int32_t*)scratch, st); if (rc) return rc;
+    int64_t nt = n_bundles * (channels + 2);
+    hipLaunchKernelGGL(k_comp_accum, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, n_bundles, channels, 0,
+                       (const int32_t*)scratch, weights, feat, z, fm, dm, om);
+    LAUNCH_CHECK("k_comp_accum");
+    return GDB_OK;
+}

@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[(PT_W * PT_H + 16 * 4 + 8 * 2 + 4) * (GDB_CP / 4)];
     if ((int)blockIdx.x >= a.ntiles) {
         for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
-            cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
+            if (t % (a.V + 1) == 0 || a.src_exts)
+                cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
         return;
     }
     float* tile = (float*)tile4;
@@ -217,8 +218,12 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
 
 extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
-    rc = gdb_check_frame(cfg, f, true); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
     if (!ws) return gdb_fail(GDB_E_BADARG, "workspace is NULL");
+    // target camera + scene range are always needed; the source side (views, feature map) may be absent
+    // when only build_rays / sample will follow (the reference has no source views at that point either)
+    if (!f->d_tar_exts || !f->d_tar_ints || !f->d_near_far) return gdb_fail(GDB_E_BADARG, "frame has a NULL target-camera pointer");
+    if ((f->d_src_exts == nullptr) != (f->d_src_ints == nullptr)) return gdb_fail(GDB_E_BADARG, "source extrinsics and intrinsics must come together");
     WsLayout L = ws_layout(*cfg, *f);
     if (ws_bytes < L.total) return gdb_fail(GDB_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
     hipStream_t st = (hipStream_t)stream_;
@@ -226,7 +231,7 @@ extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, si
     a.B = f->B; a.V = f->V; a.H = f->H; a.W = f->W; a.levels = L.levels;
     if (a.levels > 3) return gdb_fail(GDB_E_BADARG, "max_mipmap_level > 3 unsupported by the tile kernel");
     a.tilesX = (f->W + PT_W - 1) / PT_W; a.tilesY = (f->H + PT_H - 1) / PT_H;
-    a.ntiles = a.tilesX * a.tilesY * f->B * f->V;
+    a.ntiles = f->d_img_feat ? a.tilesX * a.tilesY * f->B * f->V : 0;
     a.b = cfg->bundle_size; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { a.lvlH[i] = L.lvlH[i]; a.lvlW[i] = L.lvlW[i]; a.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     a.pyrStride = (unsigned)L.pyrStride;
@@ -393,7 +398,8 @@ static int sample_impl(const DevFrame& d, const WsLayout& L, void* ws, float* ra
 extern "C" int gdb_sample(const GdbConfig* cfg, const GdbFrame* f, void* ws, float* rays_xyz, float* uvd, float* z_vals,
                           float* ball, int64_t* indices, int64_t* per_batch, int32_t* spb, int64_t* total, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
-    rc = gdb_check_frame(cfg, f, true); if (rc) return rc;
+    rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
+    if (!f->d_depth_range || !f->d_vol_range) return gdb_fail(GDB_E_BADARG, "frame has a NULL depth_range / vol_range pointer");
     if (!ws || !rays_xyz || !uvd || !z_vals || !ball || !indices || !per_batch || !spb || !total)
         return gdb_fail(GDB_E_BADARG, "NULL pointer");
     WsLayout L = ws_layout(*cfg, *f);

@@ -113,21 +113,29 @@ class HotPathEngine:
         self.weights = torch.from_numpy(host).to(self.device)
 
     # ---- per-frame preparation -----------------------------------------------------------
-    def prepare(self, frame: Dict[str, torch.Tensor]) -> None:
-        """Validate shapes on the host, then build the camera block and the feature pyramid."""
-        si = frame["src_images"]
-        if si.dim() != 5:
-            raise ValueError("src_images must be (B,V,3,Ho,Wo)")
-        B, V, _, Ho, Wo = si.shape
+    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None) -> None:
+        """Validate shapes on the host, then build the camera block and the feature pyramid.  A frame
+        without the source side (only tar_ext, tar_int, near_far [, depth_range, vol_range]; pass
+        `im_size=(Ho,Wo)`) prepares the target camera alone — enough for build_rays / sample."""
         b = self.b
+        if "src_images" in frame:
+            si = frame["src_images"]
+            if si.dim() != 5:
+                raise ValueError("src_images must be (B,V,3,Ho,Wo)")
+            B, V, _, Ho, Wo = si.shape
+            D = frame["feat_volume"].shape[2]
+        else:
+            (Ho, Wo), B, V, D = im_size, frame["tar_ext"].shape[0], 1, 1
         if Ho % b or Wo % b:
             raise ValueError(f"image {Ho}x{Wo} not divisible by bundle_size {b}")
         H, W = Ho // b, Wo // b
-        D = frame["feat_volume"].shape[2]
         dims = (B, V, Ho, Wo, H, W, D, self.cfg.feat_dim, self.cfg.voxel_dim)
         for name, shp in _FRAME_SHAPES.items():
-            _chk(frame[name], name, shp(*dims))
-        f = GdbFrame(B, V, Ho, Wo, H, W, D, *(frame[k].data_ptr() for k in (
+            if name in frame:
+                _chk(frame[name], name, shp(*dims))
+            elif "src_images" in frame or name in ("tar_ext", "tar_int", "near_far"):
+                raise KeyError(name)
+        f = GdbFrame(B, V, Ho, Wo, H, W, D, *(_ptr(frame.get(k)) for k in (
             "src_images", "img_feat", "feat_volume", "depth_range", "vol_range", "src_exts", "src_ints",
             "tar_ext", "tar_int", "near_far")))
         need = C.c_size_t()
@@ -219,6 +227,27 @@ class HotPathEngine:
                                           indices.data_ptr(), _ptr(total), n, n_bundles, ch, weights.data_ptr(), bf.data_ptr(),
                                           depth.data_ptr(), opac.data_ptr(), scratch.data_ptr(), self._stream()))
         return weights, bf, depth, opac
+
+    def render_weights(self, sigma: torch.Tensor, indices: torch.Tensor, n_bundles: int, total: Optional[torch.Tensor] = None):
+        n = sigma.shape[0]
+        _chk(sigma, "sigma", (n,)); _chk(indices, "indices", (n,), torch.int64)
+        weights = torch.zeros((n,), device=self.device)
+        scratch = torch.empty((2 * n_bundles,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.gdb_render_weights(C.byref(self.cfg), sigma.data_ptr(), indices.data_ptr(), _ptr(total), n, n_bundles,
+                                               weights.data_ptr(), scratch.data_ptr(), self._stream()))
+        return weights
+
+    def accumulate(self, weights: torch.Tensor, feat: torch.Tensor, z_vals: torch.Tensor, indices: torch.Tensor, n_bundles: int,
+                   total: Optional[torch.Tensor] = None):
+        n, ch = feat.shape
+        _chk(weights, "weights", (n,)); _chk(feat, "feat", (n, ch)); _chk(z_vals, "z_vals", (n,)); _chk(indices, "indices", (n,), torch.int64)
+        dev = self.device
+        fm, dm, om = torch.empty((n_bundles, ch), device=dev), torch.empty((n_bundles,), device=dev), torch.empty((n_bundles,), device=dev)
+        scratch = torch.empty((2 * n_bundles,), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.gdb_accumulate(C.byref(self.cfg), weights.data_ptr(), feat.data_ptr(), z_vals.data_ptr(), indices.data_ptr(),
+                                           _ptr(total), n, n_bundles, ch, fm.data_ptr(), dm.data_ptr(), om.data_ptr(), scratch.data_ptr(),
+                                           self._stream()))
+        return fm, dm, om
 
     def render_unfused(self):
         """build_rays → sample → encode → MLP → composite through the operator mirrors (all fp32)."""

@@ -99,7 +99,9 @@ int gdb_pack_weights(const GdbConfig* cfg, const float* const h_tensors[18], flo
 /* ---- per-frame preparation ---------------------------------------------------------- */
 /* Camera block (matrix inverses, ray matrix, pixel radii: bundle_sampler.py:67-74,304-313)
  * and the channel-last mip pyramid of img_feat (what nvdiffrast.texture builds on every
- * call, bundle_sampler.py:355-359).  The workspace also reserves room for the per-bundle
+ * call, bundle_sampler.py:355-359).  d_tar_exts, d_tar_ints, d_near_far are required; the source
+ * side (d_src_exts + d_src_ints, d_img_feat) may be NULL when only gdb_build_rays / gdb_sample follow.
+ * The workspace also reserves room for the per-bundle
  * sample counts and their exclusive scan, which gdb_sample fills
  * (bundle_sampler.py:179,182-189). */
 int gdb_prepare(const GdbConfig* cfg, const GdbFrame* frame, void* d_workspace, size_t workspace_bytes,
@@ -147,6 +149,20 @@ int gdb_composite(const GdbConfig* cfg, const float* d_sigma, const float* d_fea
                   const int64_t* d_indices, const int64_t* d_total, int64_t n_alloc, int64_t n_bundles,
                   int32_t channels, float* d_weights, float* d_bundle_feat, float* d_depth, float* d_opacity,
                   void* d_scratch_2xnbundles_i32, void* stream);
+
+/* render_weight_from_density alone, networks/gdb_nerf/utils.py:19-43 (alpha = 1-exp(-sigma);
+ * nerfacc.volrend.render_weight_from_alpha :35; per-bundle normalisation :38-41).
+ * d_scratch: 2*n_bundles int32. */
+int gdb_render_weights(const GdbConfig* cfg, const float* d_sigma, const int64_t* d_indices, const int64_t* d_total,
+                       int64_t n_alloc, int64_t n_bundles, float* d_weights, void* d_scratch_2xnbundles_i32, void* stream);
+
+/* accumulate_value_along_rays alone, networks/gdb_nerf/utils.py:88-121
+ * (nerfacc.volrend.accumulate_along_rays :110): segmented sum of weights * [feat | z | 1].  z_vals are
+ * used as given (the caller applies inv_depth as Network.render_bundles does). */
+int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_feat, const float* d_z_vals,
+                   const int64_t* d_indices, const int64_t* d_total, int64_t n_alloc, int64_t n_bundles, int32_t channels,
+                   float* d_feat_map, float* d_depth_map, float* d_opacity_map, void* d_scratch_2xnbundles_i32,
+                   void* stream);
 
 /* ---- production entry ---------------------------------------------------------------- */
 /* The whole hot-path section of Network.forward (network.py:145-169: build_rays → sample →

@@ -1,0 +1,133 @@
+"""The reference's plugin surface (make_network / make_evaluator / config YAMLs) re-authored on the
+MI355X engine: checkpoint compatibility and CNN parity on the CPU, whole-network parity on the GPU,
+against fixture F7 (the reference's own Network.forward, tests/golden/make_golden_network.py)."""
+import numpy as np
+import pytest
+import torch
+
+import gdb_oracle as oracle
+from conftest import load_golden, max_abs
+from gdb_nerf_amd.configs import make_cfg
+from gdb_nerf_amd.evaluators import make_evaluator
+from gdb_nerf_amd.evaluators.gdb_nerf import psnr as ev_psnr, ssim as ev_ssim
+from gdb_nerf_amd.networks import make_network
+
+
+@pytest.fixture(scope="module")
+def f7():
+    return load_golden("F7_network")
+
+
+def _state_dict(fx):
+    return {k[3:]: torch.from_numpy(np.asarray(v, dtype=np.float32) if v.dtype == np.float16 else v) for k, v in fx.items() if k.startswith("sd.")}
+
+
+def _net(fx, **opts):
+    flat = [x for kv in opts.items() for x in (kv[0], str(kv[1]))]
+    net = make_network(make_cfg("configs/dtu_eval.yaml", flat)).eval()
+    missing = net.load_state_dict(_state_dict(fx), strict=True)  # a reference checkpoint loads unchanged
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net
+
+
+def test_config_precedence_and_paths():
+    c = make_cfg("configs/dtu_eval.yaml", ["nerf.max_num_samples", "5", "exp_name", "x"])
+    assert c.nerf.max_num_samples == 5 and c.nerf.is_adaptive is True and c.nerf.bundle_size == 2  # override > YAML > parent
+    assert c.mvs.num_depth == [64, 8] and c.mvs.inv_depth == [True, False] and c.fpn.feat_dims == [32, 16, 8]
+    assert c.network_path == "networks/gdb_nerf/network.py" and c.evaluator_path == "evaluators/gdb_nerf.py"
+    assert c.result_dir.endswith("gdb_nerf/x/default")
+    n = make_cfg("configs/nerf_eval.yaml")
+    assert n.nerf.max_num_samples == 6 and n.nerf.reweighting is True
+    l = make_cfg("configs/llff_eval.yaml")
+    assert l.mvs.num_depth == [36, 8] and l.test.eval_center is True
+
+
+def test_network_has_reference_checkpoint_layout(f7):
+    net = _net(f7)
+    assert [n for n, _ in net.named_children()] == ["feature_net", "depth_net", "nerf", "upsampler"]
+    assert sum(p.numel() for p in net.parameters()) == 37336 + 388562 + 11930 + 524483
+    keys = set(net.state_dict())
+    for k in ("nerf.view_fc.0.weight", "nerf.weight.2.bias", "depth_net.nerfs.0.color.2.weight", "depth_net.cost_regs.1.conv9.0.weight",
+              "upsampler.blocks.2.se.fc.2.weight", "feature_net.inner2.bias"):
+        assert k in keys
+    with pytest.raises(ValueError, match="power of 2"):
+        make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "3"]))
+
+
+def test_cnns_match_reference_on_cpu(f7):
+    """Upstream / downstream CNNs (PyTorch, out of the hot path) reproduce the reference's outputs."""
+    net = _net(f7)
+    t = lambda k: torch.from_numpy(f7[k])
+    with torch.no_grad():
+        src = t("src_images")
+        ms = net.feature_net(src.flatten(0, 1))
+        assert max_abs(ms[1].numpy(), f7["feat_l1"]) <= 1e-5
+        ms5 = [f.unflatten(0, (1, 3)) for f in ms]
+        d, rng, vrng, vol, _ = net.depth_net(src, ms5, t("src_exts"), t("src_ints"), t("tar_ext"), t("tar_int"), t("near_far"))
+        assert max_abs(d[0].numpy(), f7["mvs_depth0"]) <= 1e-3 * float(np.abs(f7["mvs_depth0"]).max())
+        assert max_abs(rng[-1].numpy(), f7["depth_range"]) <= 1e-4 * float(np.abs(f7["depth_range"]).max())
+        assert max_abs(vrng[-1].numpy(), f7["vol_range"]) <= 1e-4 * float(np.abs(f7["vol_range"]).max())
+        assert max_abs(vol[-1].numpy(), f7["feat_volume"]) <= 1e-4
+        assert max_abs(net.upsampler(t("dec_in")).numpy(), f7["dec_out"]) <= 1e-5
+
+
+def test_evaluator_metrics_and_surface():
+    rng = np.random.default_rng(0)
+    gt = rng.random((40, 48, 3)).astype(np.float32)
+    pred = np.clip(gt + rng.normal(0, 0.05, gt.shape), 0, 1).astype(np.float32)
+    assert abs(ev_psnr(gt, pred) - oracle.psnr(gt, pred)) < 1e-9
+    assert ev_ssim(gt, gt) == pytest.approx(1.0) and 0.5 < ev_ssim(gt, pred) < 1.0
+    cfg = make_cfg("configs/dtu_eval.yaml")
+    ev = make_evaluator(cfg)
+    batch = {"src_views": {"rgb": torch.zeros(1, 3, 3, 40, 48)}, "tar_views": {"rgb": torch.from_numpy(gt)[None], "mask": torch.ones(1, 40, 48)},
+             "meta": {"scene": ["scan114"], "tar_view": torch.tensor([0]), "frame_id": torch.tensor([0])}}
+    ev.evaluate({"rgb": torch.from_numpy(pred).permute(2, 0, 1)[None]}, batch)
+    out = ev.summarize()
+    assert set(out) == {"psnr", "ssim"} and abs(out["psnr"] - oracle.psnr(gt, pred, np.ones((40, 48), bool))) < 1e-6
+    cfg.skip_eval = True
+    assert make_evaluator(cfg) is None
+
+
+def _batch(f7, dev):
+    t = lambda k: torch.from_numpy(f7[k]).to(dev)
+    return {"src_views": {"rgb": t("src_images"), "extrinsics": t("src_exts"), "intrinsics": t("src_ints")},
+            "tar_views": {"extrinsics": t("tar_ext"), "intrinsics": t("tar_int")}, "near_far": t("near_far")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hot_path,tol", [("mirrors", 5e-4), ("fused", 2e-3)])
+def test_network_forward_matches_reference(f7, hot_path, tol):
+    """Whole Network.forward on the MI355X (CNNs on PyTorch-ROCm, hot path on the HIP library) against
+    the reference's CPU forward with the same checkpoint."""
+    net = _net(f7, **{"nerf.hot_path": hot_path}).cuda()
+    with torch.no_grad():
+        ret, mvs_depths, blend = net(_batch(f7, "cuda"))
+    assert blend == [] and len(mvs_depths) == 2
+    assert tuple(ret["rgb"].shape) == (1, 3, 64, 96) and tuple(ret["nerf_depth"].shape) == (1, 64, 96)
+    e = max_abs(ret["rgb"].cpu().numpy(), f7["rgb"])
+    print(f"network forward ({hot_path}): max |rgb - reference| = {e:.3e}")
+    assert e <= tol
+    assert max_abs(ret["mvs_depth"].cpu().numpy(), f7["mvs_depth"]) <= 1e-3 * float(np.abs(f7["mvs_depth"]).max())
+    assert max_abs(ret["nerf_depth"].cpu().numpy(), f7["nerf_depth"]) <= 2e-3 * float(np.abs(f7["nerf_depth"]).max())
+    assert max_abs(ret["opacity"].cpu().numpy(), f7["opacity"]) <= 1e-4
+    gt = np.clip(np.transpose(f7["rgb"][0], (1, 2, 0)) + np.random.default_rng(1).normal(0, 0.03, (64, 96, 3)), 0, 1)
+    d_psnr = abs(oracle.psnr(gt, np.transpose(ret["rgb"][0].cpu().numpy(), (1, 2, 0))) - oracle.psnr(gt, np.transpose(f7["rgb"][0], (1, 2, 0))))
+    assert d_psnr <= 0.05  # north_star: PSNR within 0.05 dB of the reference path
+
+
+@pytest.mark.gpu
+def test_sampler_mirror_has_reference_semantics():
+    """BundleSampler mirror: reference call order, dtypes (float counts on the adaptive path) and errors."""
+    from gdb_nerf_amd.networks.gdb_nerf.bundle_sampler import BundleSampler
+    fx = load_golden("F2_sample")
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s = BundleSampler(64, 3)
+    with pytest.raises(ValueError, match="build_rays"):
+        s.sample(c(fx["depth_range"]), c(fx["vol_range"]), 2, 3, False, True)
+    s.build_rays(c(fx["tar_ext"]), c(fx["tar_int"]), (32, 48), c(fx["near_far"][:, 0]), c(fx["near_far"][:, 1]))
+    out = s.sample(c(fx["depth_range"]), c(fx["vol_range"]), 2, 3, False, True)
+    assert out[6].dtype == torch.float32 and out[5].dtype == torch.float32 and out[4].dtype == torch.int64
+    assert np.array_equal(out[4].cpu().numpy(), fx["ada3_indices"])
+    assert max_abs(out[0].cpu().numpy(), fx["ada3_rays_xyz"]) <= 2e-3
+    out = s.sample(c(fx["depth_range"]), c(fx["vol_range"]), 2, 6, False, False)
+    assert out[6].dtype == torch.int32 and np.array_equal(out[4].cpu().numpy(), fx["fix6_indices"])
