@@ -163,12 +163,18 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 #else
 #define BLVOL
 #endif
+#ifdef GDB_DEBUG_STAMPS
+#define STAMP(i) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) ((unsigned long long*)dbg)[(size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #define PHASE_FENCE() asm volatile("" ::: "memory")
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
-constexpr int STAGE_T = 512;                 // floats: two tail fragments of one view (2 x 1 KiB)
+constexpr int STAGE_T = 384;                 // floats: tail fragment 0 (64 lanes x 16 B) + the lower half of fragment 1 (its upper half is zero)
 #ifdef GDB_DEBUG_CHECK
 constexpr int STAGE_B = 32 * 32;             // debug: a spare row 31 holds a second copy of row 7
 #else
@@ -184,7 +190,7 @@ constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot 
 struct FusedArgs {
     DevFrame f;
     const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nblk, alias, lds_floats;
+    int row_begin, nrows, nseg, nblk, alias, lds_floats, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
     float* bf; float* depth; float* opac;
     unsigned* dbg;
 };
@@ -289,11 +295,20 @@ __device__ __forceinline__ void rgb_fetch_fast(const float* __restrict__ img, in
 
 extern __shared__ float4 smem4[];
 
+// k-step 1 of the staged tail vector: only half 0 carries data (rgb tail + dir); half 1 is zero.
+__device__ __forceinline__ half8 load_t1(const float* __restrict__ st, int j, int h) {
+    half8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f;
+    half8 v = ((const half8*)st)[64 + j];
+    return h == 0 ? v : z;
+}
+
 // g_v = feat ⊕ rgb + ReLU(view_fc(dir)) of one staged view, in accumulator layout   nerf.py:69-71
 __device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const half8 a_view, const f32x16& b_view,
                                          int lane, int j, int h) {
     const float* bl = st + STAGE_T;
-    half8 T1 = ((const half8*)st)[64 + lane];
+    half8 T1 = load_t1(st, j, h);
     f32x16 g = MFMA(a_view, T1, b_view);
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -311,7 +326,7 @@ __device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const hal
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
-                                            float ball, const float* __restrict__ tc, f32x16& tv, float rgb[2][3]) {
+                                            float ball, const float* __restrict__ tc, f32x16& tv, float rgb[2][3], int skip) {
     const float* sc = src_cam(f, bi, v);
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
 #pragma unroll
@@ -323,7 +338,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 #pragma unroll
         for (int r = 0; r < 3; ++r) im[r] = fmaf(sc[S_K + 3 * r], cm[0], fmaf(sc[S_K + 3 * r + 1], cm[1], sc[S_K + 3 * r + 2] * cm[2]));
         float iz = frcp(fmaxf(im[2], 1e-6f));
-        rgb_fetch_fast(img, f.Ho, f.Wo, im[0] * iz, im[1] * iz, rgb[e]);
+        if (!(skip & 1)) rgb_fetch_fast(img, f.Ho, f.Wo, im[0] * iz, im[1] * iz, rgb[e]);
     }
     // sphere centre in the camera frame: the mean of the sub-ray points maps to the mean of their images   :340
     float cc[3];
@@ -351,9 +366,9 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     {
         unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : f.lvlOff[3]));
         Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
-        taps_fetch(pyr, t, h, acc);
+        if (!(skip & 2)) taps_fetch(pyr, t, h, acc);
     }
-    if (frac > 0.f) {
+    if (frac > 0.f && !(skip & 2)) {
         unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : f.lvlOff[3]);
         Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
         taps_fetch(pyr, t, h, acc);
@@ -377,13 +392,14 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 // One sample slot k of the workgroup's 32 bundles: gather, MLP, record for the composite.
 __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __restrict__ mf, float* stage,
                                             float* ck, const float* __restrict__ tc, int k, int bi, int row,
-                                            int x, bool inrow, int lane, int j, int h, unsigned* dbg) {
+                                            int x, bool inrow, int lane, int j, int h, unsigned* dbg, int skip) {
     const int V = f.V;
     {
         float z;
         bool act;
         half8 H1;  // vox channels 4h..4h+3 as the k-step-1 operand of [vox | im]
         // ======================= gather: all a view contributes goes to LDS =======================
+        STAMP(0);
         {
             Bundle<4> q;
             load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
@@ -397,7 +413,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
             float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
-            if (act) {
+            if (act && !(skip & 4)) {
                 float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
                 float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
                 float wx = gx - xf, wy = gy - yf, wz = gz - zf;
@@ -423,6 +439,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+            STAMP(1);
             float xyzh[2][3];  // this half's two sub-ray points
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -435,7 +452,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
 #pragma unroll
                 for (int i = 0; i < 16; ++i) tv[i] = 0.f;
                 float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-                if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, tv, rgb);
+                if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, tv, rgb, skip);
                 BLVOL float* bl = st + STAGE_T;
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
@@ -449,7 +466,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
                         if (ch < GDB_CFR) bl[(12 + ch) * 32 + j] = tv[4 * s + e];
                     }
                 ((half8*)st)[lane] = acc_frag<0, false>(tv);
-                ((half8*)st)[64 + lane] = acc_frag<1, false>(tv);
+                if (h == 0) ((half8*)st)[64 + j] = acc_frag<1, false>(tv);
 #ifdef GDB_DEBUG_CHECK
                 if (h == 1) bl[31 * 32 + j] = rgb[1][1];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -462,6 +479,12 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         }
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
+        STAMP(2);
+        float bacc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+        float fhv[4] = {0.f, 0.f, 0.f, 0.f}, sig = 0.f;
+        if (!(skip & 8)) {
         // ======================= MLP (nerf.py:58-115) =======================
         f32x16 base;
         {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
@@ -491,6 +514,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
         }
         PHASE_FENCE();
+        STAMP(3);
         half8 H0;
         {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
             f32x16 agg;
@@ -525,6 +549,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             H0 = acc_frag<0, true>(im);
         }
         PHASE_FENCE();
+        STAMP(4);
         half8 X00, X01, X10, X11;
         {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
             f32x16 x0 = load_tab(mf, TB_LR0, h_o);
@@ -537,7 +562,6 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
             X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
         }
         PHASE_FENCE();
-        float fhv[4], sig;
         {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
             f32x16 fh = load_tab(mf, TB_FH, h_o);
             fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
@@ -571,10 +595,8 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         hs1 = MFMA(load_frag(mf, F_W0B + 3, lane_o), H1, hs1);
         }
         PHASE_FENCE();
+        STAMP(5);
         // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
-        float bacc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
         {
             const float b_w2 = mf[TS_BW2];
             float mx = -INFINITY, den = 0.f;
@@ -582,7 +604,7 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
                 LANE_KEYS();
                 const float* st = stage + (size_t)v * STAGE_V;
                 const float* bl = st + STAGE_T;
-                half8 T0 = ((const half8*)st)[lane], T1 = ((const half8*)st)[64 + lane];
+                half8 T0 = ((const half8*)st)[lane], T1 = load_t1(st, j, h);
                 float up;
                 {
                     f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), T0, hs0);
@@ -619,6 +641,8 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         }
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
+        }
+        STAMP(6);
         // ======================= hand this slot to the composite =======================
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -643,8 +667,10 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         }
 }
 
-template <bool LOOP>
-__global__ void __launch_bounds__(256, 3) k_render_fused(FusedArgs a) {
+// LOOP = false: one slot per wave, straight-line code (WAVES = 4: up to 256 threads, 3 waves/SIMD;
+// WAVES = 8: up to 512 threads for 5..8 slots).  LOOP = true: more slots than waves fit in LDS.
+template <bool LOOP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -671,15 +697,18 @@ __global__ void __launch_bounds__(256, 3) k_render_fused(FusedArgs a) {
     const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
     float* rec0 = alias ? smem : smem + (size_t)nw * wave_fl;
     const float* tc = tar_cam(f, bi);
+    unsigned* dbg = a.dbg; (void)dbg;
 
     // [COMP_CH][COMP_LD] values, then alpha[32], wn[32] per slot
     if (LOOP) {
         for (int k = wid; k < S; k += nw)
-            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h, a.dbg);
+            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h, a.dbg, a.skip);
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
-        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h, a.dbg);
+        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h, a.dbg, a.skip);
     }
+    STAMP(7);
     __syncthreads();
+    STAMP(8);
     // transmittance weights per bundle, normalised   utils.py:35-41
     if (threadIdx.x < 32) {
         float T = 1.f, sum = 0.f;
@@ -723,6 +752,7 @@ __global__ void __launch_bounds__(256, 3) k_render_fused(FusedArgs a) {
             else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
         }
     }
+    STAMP(9);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
@@ -748,25 +778,33 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
     const size_t lds_max = 160 * 1024;
-    // at most 4 waves per workgroup (one per SIMD); with more slots than waves each wave loops
-    int nw = S <= 4 ? S : (S + (S + 3) / 4 - 1) / ((S + 3) / 4);
-    a.alias = (nw == S && per_wave >= sizeof(float) * COMP_REC && !getenv("GDB_FUSED_NO_ALIAS")) ? 1 : 0;
+    // one wave per slot up to 8 slots when LDS allows; otherwise <= 4 waves that loop over the slots
+    int nw = S <= 8 ? S : 4;
+    a.alias = (per_wave >= sizeof(float) * COMP_REC && !getenv("GDB_FUSED_NO_ALIAS")) ? 1 : 0;
     size_t fixed = a.alias ? 0 : sizeof(float) * (size_t)S * COMP_REC;
-    while (nw > 1 && fixed + nw * per_wave > lds_max) { --nw; a.alias = 0; fixed = sizeof(float) * (size_t)S * COMP_REC; }
+    if (nw != S || fixed + nw * per_wave > lds_max) {  // looping waves: balanced slot counts, separate composite records
+        a.alias = 0; fixed = sizeof(float) * (size_t)S * COMP_REC;
+        nw = S < 4 ? S : 4;
+        nw = (S + (S + nw - 1) / nw - 1) / ((S + nw - 1) / nw);
+        while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
+    }
     size_t lds = fixed + nw * per_wave;
     if (getenv("GDB_FUSED_BIG_LDS")) lds = lds_max > lds ? (size_t)atoi(getenv("GDB_FUSED_BIG_LDS")) : lds;
     if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
     a.lds_floats = (int)(lds / 4);
+    a.skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = lds_max;
     }
     unsigned grid = (unsigned)((a.nblk + 7) / 8 * 8);
-    if (nw == S) hipLaunchKernelGGL(k_render_fused<false>, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL(k_render_fused<true>, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    if (nw == S && nw <= 4) hipLaunchKernelGGL((k_render_fused<false, 4>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    else if (nw == S) hipLaunchKernelGGL((k_render_fused<false, 8>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((k_render_fused<true, 4>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
     return GDB_OK;
