@@ -156,32 +156,24 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 }
 
 // ---- device side ----------------------------------------------------------------------------
-// Compiler-only fence: weight fragments are loop-invariant global loads, and without it hipcc
-// hoists all 33 of them (132 VGPRs) to kernel entry.
-#ifdef GDB_DEBUG_VOLATILE_LDS
-#define BLVOL volatile
-#else
-#define BLVOL
-#endif
-#ifdef GDB_DEBUG_STAMPS
+// Compiler-only fence: weight fragments are loop-invariant loads, and without it hipcc hoists all
+// 33 of them (132 VGPRs) to kernel entry.
+#define PHASE_FENCE() asm volatile("" ::: "memory")
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#ifdef GDB_DEBUG_STAMPS   // diagnostic build only: per-wave s_memtime stamps (tools/stamps.py)
 #define STAMP(i) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    if (lane == 0) ((unsigned long long*)dbg)[(size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
+    if (lane == 0) ((unsigned long long*)dbg)[(size_t)(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
-#define PHASE_FENCE() asm volatile("" ::: "memory")
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat
+constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat ⊕ rgb
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
-constexpr int STAGE_T = 384;                 // floats: tail fragment 0 (64 lanes x 16 B) + the lower half of fragment 1 (its upper half is zero)
-#ifdef GDB_DEBUG_CHECK
-constexpr int STAGE_B = 32 * 32;             // debug: a spare row 31 holds a second copy of row 7
-#else
-constexpr int STAGE_B = NBLEND * 32;         // floats: blend values [31][32]
-#endif
-constexpr int STAGE_V = STAGE_T + STAGE_B;   // per (wave, view)
-constexpr int COMP_LD = 33;                  // padded bundle stride of the composite staging
+// Per (wave, view) staging in LDS: 35 fp32 rows of 32 bundles — the reference's per-view vector
+// [rgbs 12 | feat ⊕ rgb 19 | dir 4] (bundle_sampler.py:369), one row per channel.
+constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND, STAGE_ROWS = NBLEND + 4;
+constexpr int STAGE_V = STAGE_ROWS * 32;     // 1120 floats = 4480 B
+constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
 constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
 constexpr int COMP_WN = COMP_ALPHA + 32;                     // normalised weight [32]
@@ -190,7 +182,7 @@ constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot 
 struct FusedArgs {
     DevFrame f;
     const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nblk, alias, lds_floats, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
+    int row_begin, nrows, nseg, nsegs, ntiles, teams, alias, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
     float* bf; float* depth; float* opac;
     unsigned* dbg;
 };
@@ -213,7 +205,7 @@ __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
 
 // Weight fragments / tables are addressed as (uniform base + constant) + per-lane offset.  The
 // per-lane part goes through an opaque asm once per phase: otherwise hipcc materialises all ~45
-// 64-bit per-lane addresses at kernel entry (loop-invariant) and spills them.
+// per-lane addresses at kernel entry (loop-invariant) and spills them.
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off, int h) {
     return *(const f32x16*)(mf + off + h * 16);
@@ -295,29 +287,37 @@ __device__ __forceinline__ void rgb_fetch_fast(const float* __restrict__ img, in
 
 extern __shared__ float4 smem4[];
 
-// k-step 1 of the staged tail vector: only half 0 carries data (rgb tail + dir); half 1 is zero.
-__device__ __forceinline__ half8 load_t1(const float* __restrict__ st, int j, int h) {
-    half8 z;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f;
-    half8 v = ((const half8*)st)[64 + j];
-    return h == 0 ? v : z;
-}
-
-// g_v = feat ⊕ rgb + ReLU(view_fc(dir)) of one staged view, in accumulator layout   nerf.py:69-71
-__device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const half8 a_view, const f32x16& b_view,
-                                         int lane, int j, int h) {
-    const float* bl = st + STAGE_T;
-    half8 T1 = load_t1(st, j, h);
-    f32x16 g = MFMA(a_view, T1, b_view);
+// This lane's 12 staged feature values (channels 8s+4h+e, the accumulator rows it owns) and, for half
+// 0, the 4 direction values; from them the two f16 operand fragments of the per-view tail vector
+// tv[32] = [feat ⊕ rgb 19 | 0 | dir 4 at 24..27 | 0].
+struct Tail { float fv[12]; half8 T0, T1; };
+__device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, int h) {
+    Tail t;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int ch = 8 * s + 4 * h + e;
-            float fv = ch < GDB_CFR ? bl[(12 + ch) * 32 + j] : 0.f;
-            g[4 * s + e] = fv + fmaxf(g[4 * s + e], 0.f);
+            t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
         }
+    float d[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = st[(ROW_DIR + e) * 32 + j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.T0[i] = (_Float16)to_h_range(t.fv[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t.T1[i] = (_Float16)to_h_range(t.fv[8 + i]);              // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
+        t.T1[4 + i] = (_Float16)(h == 0 ? to_h_range(d[i]) : 0.f);  // dir sits at tv[24..27], owned by half 0
+    }
+    return t;
+}
+
+// g_v = feat ⊕ rgb + ReLU(view_fc(dir)) of one staged view, in accumulator layout   nerf.py:69-71
+__device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view, const f32x16& b_view) {
+    f32x16 g = MFMA(a_view, t.T1, b_view);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + fmaxf(g[i], 0.f);
 #pragma unroll
     for (int i = 12; i < 16; ++i) g[i] = 0.f;
     return g;
@@ -326,7 +326,7 @@ __device__ __forceinline__ f32x16 view_g(const float* __restrict__ st, const hal
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
-                                            float ball, const float* __restrict__ tc, f32x16& tv, float rgb[2][3], int skip) {
+                                            float ball, const float* __restrict__ tc, float4 feat[3], float dir[4], float rgb[2][3], int skip) {
     const float* sc = src_cam(f, bi, v);
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
 #pragma unroll
@@ -360,21 +360,16 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
     const float4* pyr = (const float4*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
-    float4 acc[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : f.lvlOff[3]));
         Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
-        if (!(skip & 2)) taps_fetch(pyr, t, h, acc);
+        if (!(skip & 2)) taps_fetch(pyr, t, h, feat);
     }
     if (frac > 0.f && !(skip & 2)) {
         unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : f.lvlOff[3]);
         Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
-        taps_fetch(pyr, t, h, acc);
+        taps_fetch(pyr, t, h, feat);
     }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) { tv[4 * s] = acc[s].x; tv[4 * s + 1] = acc[s].y; tv[4 * s + 2] = acc[s].z; tv[4 * s + 3] = acc[s].w; }
     // view-direction code   :362-367
     float td[3], sd[3], dd[3], dif[3], dnn[3];
 #pragma unroll
@@ -386,196 +381,182 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 #pragma unroll
     for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
     fnormalize3(dif, dnn);
-    if (h == 0) { tv[12] = dnn[0]; tv[13] = dnn[1]; tv[14] = dnn[2]; tv[15] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2]; }
+    dir[0] = dnn[0]; dir[1] = dnn[1]; dir[2] = dnn[2]; dir[3] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2];
 }
 
-// One sample slot k of the workgroup's 32 bundles: gather, MLP, record for the composite.
-__device__ __forceinline__ void render_slot(const DevFrame& f, const float* __restrict__ mf, float* stage,
-                                            float* ck, const float* __restrict__ tc, int k, int bi, int row,
-                                            int x, bool inrow, int lane, int j, int h, unsigned* dbg, int skip) {
+// Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns
+// false (and writes an empty composite record) when no lane has a sample in this slot.
+__device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, int k, int bi,
+                                            int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
     const int V = f.V;
-    {
-        float z;
-        bool act;
-        half8 H1;  // vox channels 4h..4h+3 as the k-step-1 operand of [vox | im]
-        // ======================= gather: all a view contributes goes to LDS =======================
-        STAMP(0);
-        {
-            Bundle<4> q;
-            load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
-            act = inrow && k < q.count;
-            if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
-                for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
-                if (h == 0) ck[COMP_ALPHA + j] = 0.f;
-                return;
-            }
-            float dn, ball, xyz[4][3], ctr[3];
-            bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
+    Bundle<4> q;
+    load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
+    act = inrow && k < q.count;
+    if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
+        for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
+        if (h == 0) ck[COMP_ALPHA + j] = 0.f;
+        return false;
+    }
+    float dn, ball, xyz[4][3], ctr[3];
+    bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
-            float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
-            if (act && !(skip & 4)) {
-                float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
-                float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
-                float wx = gx - xf, wy = gy - yf, wz = gz - zf;
-                int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
-                const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
-                const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
-                const unsigned cb = 4u * (unsigned)h * cs;
+    float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
+    if (act && !(skip & 4)) {
+        float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
+        float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
+        float wx = gx - xf, wy = gy - yf, wz = gz - zf;
+        int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+        const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
+        const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
+        const unsigned cb = 4u * (unsigned)h * cs;
 #pragma unroll
-                for (int dz = 0; dz < 2; ++dz)
+        for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            int xx = min(x0 + dx, f.W - 1), yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
-                            // a tap clamped at the far edge carries weight 0 (its fraction is 0 there)
-                            float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                            unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xx);
+                for (int dx = 0; dx < 2; ++dx) {
+                    int xx = min(x0 + dx, f.W - 1), yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
+                    // a tap clamped at the far edge carries weight 0 (its fraction is 0 there)
+                    float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xx);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) vox[c] = fmaf(vol[off + c * cs], wgt, vox[c]);
-                        }
-            }
+                    for (int c = 0; c < 4; ++c) vox[c] = fmaf(vol[off + c * cs], wgt, vox[c]);
+                }
+    }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
+    for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
-            STAMP(1);
-            float xyzh[2][3];  // this half's two sub-ray points
+    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+    float xyzh[2][3];  // this half's two sub-ray points
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
+        for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
 
-            for (int v = 0; v < V; ++v) {
-                float* st = stage + (size_t)v * STAGE_V;
-                f32x16 tv;
+    for (int v = 0; v < V; ++v) {
+        float* st = stage + (size_t)v * STAGE_V;
+        float4 feat[3];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) tv[i] = 0.f;
-                float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-                if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, tv, rgb, skip);
-                BLVOL float* bl = st + STAGE_T;
+        for (int s = 0; s < 3; ++s) feat[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dir[4] = {0.f, 0.f, 0.f, 0.f};
+        float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, feat, dir, rgb, skip);
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) bl[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+            for (int c = 0; c < 3; ++c) st[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+        const float* ff = (const float*)feat;
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int ch = 8 * s + 4 * h + e;
-                        if (ch < GDB_CFR) bl[(12 + ch) * 32 + j] = tv[4 * s + e];
-                    }
-                ((half8*)st)[lane] = acc_frag<0, false>(tv);
-                if (h == 0) ((half8*)st)[64 + j] = acc_frag<1, false>(tv);
-#ifdef GDB_DEBUG_CHECK
-                if (h == 1) bl[31 * 32 + j] = rgb[1][1];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (h == 1 && dbg) {
-                    float rb = ((volatile float*)bl)[7 * 32 + j];
-                    if (__float_as_uint(rb) != __float_as_uint(rgb[1][1])) atomicAdd(dbg + 0, 1u);
-                }
-#endif
+            for (int e = 0; e < 4; ++e) {
+                int ch = 8 * s + 4 * h + e;
+                if (ch < GDB_CFR) st[(ROW_FEAT + ch) * 32 + j] = ff[4 * s + e];
+            }
+        if (h == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[(ROW_DIR + e) * 32 + j] = dir[e];
+        }
+    }
+    return true;
+}
+
+// NeRF MLP (nerf.py:58-115) of one slot from its staged views; writes the slot's composite record.
+// `mf` = MFMA section of the packed weights, in global memory or (LDS-resident variant) in LDS.
+__device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
+                                         const half8 H1, int lane, int j, int h, unsigned* dbg) {
+    const int V = f.V;
+    f32x16 base;
+    {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+        f32x16 mean, m2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
+        const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
+        const half8 a_view = load_frag(mf, F_VIEW, lane_o);
+        for (int v = 0; v < V; ++v) {
+            f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view, b_view);
+            float inv = frcp((float)(v + 1));
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float d = g[i] - mean[i];
+                mean[i] = fmaf(d, inv, mean[i]);
+                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        PHASE_FENCE();
-        STAMP(2);
-        float bacc[16];
+        float iv = 1.f / (float)(V - 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-        float fhv[4] = {0.f, 0.f, 0.f, 0.f}, sig = 0.f;
-        if (!(skip & 8)) {
-        // ======================= MLP (nerf.py:58-115) =======================
-        f32x16 base;
-        {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
-            f32x16 mean, m2;
+        for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
+        // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
+        base = load_tab(mf, TB_GLOB, h_o);
+        base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), base);
+        base = MFMA(load_frag(mf, F_GVAR + 1, lane_o), (acc_frag<1, false>(m2)), base);
+        base = MFMA(load_frag(mf, F_GMEAN, lane_o), (acc_frag<0, false>(mean)), base);
+        base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
+    }
+    PHASE_FENCE();
+    STAMP(3);
+    half8 H0;
+    {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
+        f32x16 agg;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-            const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
-            const half8 a_view = load_frag(mf, F_VIEW, lane_o);
-            for (int v = 0; v < V; ++v) {
-                f32x16 g = view_g(stage + (size_t)v * STAGE_V, a_view, b_view, lane, j, h);
-                float inv = 1.f / (float)(v + 1);
+        for (int i = 0; i < 16; ++i) agg[i] = 0.f;
+        const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
+        const half8 a_view = load_frag(mf, F_VIEW, lane_o);
+        const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
+        const float b_agg = mf[TS_BAGG];
+        float mx = -INFINITY, den = 0.f;
+        for (int v = 0; v < V; ++v) {
+            f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view, b_view);
+            f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
+            G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
+            float sp = dot16_relu(G, load_tab(mf, TD_AGG, h_o));
+            float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
+            float mn = fmaxf(mx, sv);
+            float sc_old = __expf(mx - mn), e = __expf(sv - mn);
+            den = den * sc_old + e;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    float d = g[i] - mean[i];
-                    mean[i] = fmaf(d, inv, mean[i]);
-                    m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
-                }
-            }
-            float iv = 1.f / (float)(V - 1);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
-            // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-            base = load_tab(mf, TB_GLOB, h_o);
-            base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), base);
-            base = MFMA(load_frag(mf, F_GVAR + 1, lane_o), (acc_frag<1, false>(m2)), base);
-            base = MFMA(load_frag(mf, F_GMEAN, lane_o), (acc_frag<0, false>(mean)), base);
-            base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
+            for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
+            mx = mn;
         }
-        PHASE_FENCE();
-        STAMP(3);
-        half8 H0;
-        {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-            f32x16 agg;
+        float r = frcp(den);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) agg[i] = 0.f;
-            const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
-            const half8 a_view = load_frag(mf, F_VIEW, lane_o);
-            const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
-            const float b_agg = mf[TS_BAGG];
-            float mx = -INFINITY, den = 0.f;
-            for (int v = 0; v < V; ++v) {
-                f32x16 g = view_g(stage + (size_t)v * STAGE_V, a_view, b_view, lane, j, h);
-                f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
-                G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
-                float sp = dot16_relu(G, load_tab(mf, TD_AGG, h_o));
-                float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
-                float mn = fmaxf(mx, sv);
-                float sc_old = __expf(mx - mn), e = __expf(sv - mn);
-                den = den * sc_old + e;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
-                mx = mn;
-            }
-            float r = 1.f / den;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) agg[i] *= r;
-            PHASE_FENCE();
-            const int lane_o2 = opaque(lane), h_o2 = lane_o2 >> 5;
-            f32x16 im = load_tab(mf, TB_FC, h_o2);  // nerf.py:82
-            im = MFMA(load_frag(mf, F_FC, lane_o2), (acc_frag<0, false>(agg)), im);
-            im = MFMA(load_frag(mf, F_FC + 1, lane_o2), (acc_frag<1, false>(agg)), im);
-            H0 = acc_frag<0, true>(im);
-        }
+        for (int i = 0; i < 16; ++i) agg[i] *= r;
         PHASE_FENCE();
-        STAMP(4);
-        half8 X00, X01, X10, X11;
-        {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-            f32x16 x0 = load_tab(mf, TB_LR0, h_o);
-            x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, x0);
-            x0 = MFMA(load_frag(mf, F_LR0 + 1, lane_o), H1, x0);
-            X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
-            f32x16 x1 = load_tab(mf, TB_LR0 + 32, h_o);
-            x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, x1);
-            x1 = MFMA(load_frag(mf, F_LR0 + 3, lane_o), H1, x1);
-            X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
-        }
-        PHASE_FENCE();
-        {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-            f32x16 fh = load_tab(mf, TB_FH, h_o);
-            fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
-            fh = MFMA(load_frag(mf, F_FH + 1, lane_o), X01, fh);
-            fh = MFMA(load_frag(mf, F_FH + 2, lane_o), X10, fh);
-            fh = MFMA(load_frag(mf, F_FH + 3, lane_o), X11, fh);
+        const int lane_o2 = opaque(lane), h_o2 = lane_o2 >> 5;
+        f32x16 im = load_tab(mf, TB_FC, h_o2);  // nerf.py:82
+        im = MFMA(load_frag(mf, F_FC, lane_o2), (acc_frag<0, false>(agg)), im);
+        im = MFMA(load_frag(mf, F_FC + 1, lane_o2), (acc_frag<1, false>(agg)), im);
+        H0 = acc_frag<0, true>(im);
+    }
+    PHASE_FENCE();
+    STAMP(4);
+    half8 X00, X01, X10, X11;
+    {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
+        f32x16 x0 = load_tab(mf, TB_LR0, h_o);
+        x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, x0);
+        x0 = MFMA(load_frag(mf, F_LR0 + 1, lane_o), H1, x0);
+        X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
+        f32x16 x1 = load_tab(mf, TB_LR0 + 32, h_o);
+        x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, x1);
+        x1 = MFMA(load_frag(mf, F_LR0 + 3, lane_o), H1, x1);
+        X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
+    }
+    PHASE_FENCE();
+    float fhv[4], sig;
+    {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
+        f32x16 fh = load_tab(mf, TB_FH, h_o);
+        fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
+        fh = MFMA(load_frag(mf, F_FH + 1, lane_o), X01, fh);
+        fh = MFMA(load_frag(mf, F_FH + 2, lane_o), X10, fh);
+        fh = MFMA(load_frag(mf, F_FH + 3, lane_o), X11, fh);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fhv[i] = fmaxf(fh[i], 0.f);
-            sig = fh[4];
-        }
-        PHASE_FENCE();
-        // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
-        f32x16 hs0, hs1;
-        {   LANE_KEYS();
+        for (int i = 0; i < 4; ++i) fhv[i] = fmaxf(fh[i], 0.f);
+        sig = fh[4];
+    }
+    PHASE_FENCE();
+    // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
+    f32x16 hs0, hs1;
+    {   LANE_KEYS();
         hs0 = load_tab(mf, TB_W0, h_o);
         hs0 = MFMA(load_frag(mf, F_W0A + 0, lane_o), X00, hs0);
         hs0 = MFMA(load_frag(mf, F_W0A + 1, lane_o), X01, hs0);
@@ -583,9 +564,9 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         hs0 = MFMA(load_frag(mf, F_W0A + 3, lane_o), X11, hs0);
         hs0 = MFMA(load_frag(mf, F_W0B + 0, lane_o), H0, hs0);
         hs0 = MFMA(load_frag(mf, F_W0B + 1, lane_o), H1, hs0);
-        }
-        PHASE_FENCE();
-        {   LANE_KEYS();
+    }
+    PHASE_FENCE();
+    {   LANE_KEYS();
         hs1 = load_tab(mf, TB_W0 + 32, h_o);
         hs1 = MFMA(load_frag(mf, F_W0A + 4, lane_o), X00, hs1);
         hs1 = MFMA(load_frag(mf, F_W0A + 5, lane_o), X01, hs1);
@@ -593,158 +574,170 @@ __device__ __forceinline__ void render_slot(const DevFrame& f, const float* __re
         hs1 = MFMA(load_frag(mf, F_W0A + 7, lane_o), X11, hs1);
         hs1 = MFMA(load_frag(mf, F_W0B + 2, lane_o), H0, hs1);
         hs1 = MFMA(load_frag(mf, F_W0B + 3, lane_o), H1, hs1);
-        }
-        PHASE_FENCE();
-        STAMP(5);
-        // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
-        {
-            const float b_w2 = mf[TS_BW2];
-            float mx = -INFINITY, den = 0.f;
-            for (int v = 0; v < V; ++v) {
-                LANE_KEYS();
-                const float* st = stage + (size_t)v * STAGE_V;
-                const float* bl = st + STAGE_T;
-                half8 T0 = ((const half8*)st)[lane], T1 = load_t1(st, j, h);
-                float up;
-                {
-                    f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), T0, hs0);
-                    hv = MFMA(load_frag(mf, F_W0C + 1, lane_o), T1, hv);
-                    up = dot16_relu(hv, load_tab(mf, TD_W2, h_o));
-                }
-                {
-                    f32x16 hv = MFMA(load_frag(mf, F_W0C + 2, lane_o), T0, hs1);
-                    hv = MFMA(load_frag(mf, F_W0C + 3, lane_o), T1, hv);
-                    up += dot16_relu(hv, load_tab(mf, TD_W2 + 32, h_o));
-                }
-                float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
-                float mn = fmaxf(mx, uv);
-                float sc_old = __expf(mx - mn), e = __expf(uv - mn);
-                den = den * sc_old + e;
+    }
+    PHASE_FENCE();
+    STAMP(5);
+    // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
+    float bacc[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int c = 16 * h + i;
-                    float val = c < NBLEND ? bl[c * 32 + j] : 0.f;
-                    bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
-                }
-                mx = mn;
-#ifdef GDB_DEBUG_CHECK
-                if (h == 0 && dbg) {
-                    float r7 = ((volatile const float*)bl)[7 * 32 + j], r31 = ((volatile const float*)bl)[31 * 32 + j];
-                    if (__float_as_uint(r7) != __float_as_uint(r31)) atomicAdd(dbg + 1, 1u);
-                }
-#endif
-                PHASE_FENCE();
+    for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+    {
+        const float b_w2 = mf[TS_BW2];
+        float mx = -INFINITY, den = 0.f;
+        for (int v = 0; v < V; ++v) {
+            LANE_KEYS();
+            const float* st = stage + (size_t)v * STAGE_V;
+            const Tail t = load_tail(st, j, h);
+            float up;
+            {
+                f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), t.T0, hs0);
+                hv = MFMA(load_frag(mf, F_W0C + 1, lane_o), t.T1, hv);
+                up = dot16_relu(hv, load_tab(mf, TD_W2, h_o));
             }
-            float r = 1.f / den;
+            {
+                f32x16 hv = MFMA(load_frag(mf, F_W0C + 2, lane_o), t.T0, hs1);
+                hv = MFMA(load_frag(mf, F_W0C + 3, lane_o), t.T1, hv);
+                up += dot16_relu(hv, load_tab(mf, TD_W2 + 32, h_o));
+            }
+            float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
+            float mn = fmaxf(mx, uv);
+            float sc_old = __expf(mx - mn), e = __expf(uv - mn);
+            den = den * sc_old + e;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bacc[i] *= r;
+            for (int i = 0; i < 16; ++i) {
+                int c = 16 * h + i;
+                float val = c < NBLEND ? st[c * 32 + j] : 0.f;
+                bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
+            }
+            mx = mn;
+            PHASE_FENCE();
         }
-        __builtin_amdgcn_wave_barrier();
-        PHASE_FENCE();
-        }
-        STAMP(6);
-        // ======================= hand this slot to the composite =======================
+        float r = frcp(den);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int c = 16 * h + i;
-            if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
-        }
+        for (int i = 0; i < 16; ++i) bacc[i] *= r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    STAMP(6);
+    // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fhv[i] : 0.f;
-        if (h == 0) {
-            float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
-            ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
-            ck[COMP_ALPHA + j] = act ? 1.f - __expf(-softplus_t20(sig)) : 0.f;  // utils.py:34
-        }
-#ifdef GDB_DEBUG_CHECK
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h == 0 && dbg) {
-            float rb = ((volatile float*)ck)[7 * COMP_LD + j];
-            float want = act ? bacc[7] : 0.f;
-            if (__float_as_uint(rb) != __float_as_uint(want)) atomicAdd(dbg + 2, 1u);
-        }
-#endif
-        }
+    for (int i = 0; i < 16; ++i) {
+        int c = 16 * h + i;
+        if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fhv[i] : 0.f;
+    if (h == 0) {
+        float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
+        ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
+        ck[COMP_ALPHA + j] = act ? 1.f - __expf(-softplus_t20(sig)) : 0.f;  // utils.py:34
+    }
 }
 
-// LOOP = false: one slot per wave, straight-line code (WAVES = 4: up to 256 threads, 3 waves/SIMD;
-// WAVES = 8: up to 512 threads for 5..8 slots).  LOOP = true: more slots than waves fit in LDS.
-template <bool LOOP, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
+// Workgroup = `teams` segments x S sample slots (one wave per slot); LOOP: one segment, waves loop
+// over slots.  LDSW: the MFMA section of the weights is copied to LDS once per workgroup and shared.
+template <bool LDSW, bool LOOP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 4) ? 2 : 3)) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int V = f.V, S = f.S_max;
-    const float* __restrict__ mf = a.pw + PW_FP32_FLOATS;
-
-    // XCD-aware block order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one
-    // contiguous band of segments so vertically adjacent rows hit the same L2.
-    const int chunk = (a.nblk + 7) >> 3;
-    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (lb >= a.nblk) return;  // whole workgroup leaves together
-    const int seg = lb % a.nseg, rr = lb / a.nseg;
-    const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
-    const int x = seg * 32 + j;
-    const bool inrow = x < f.W;
-
-    // LDS: per-wave staging [V][STAGE_V], then (unless aliased) composite staging.  When every
-    // wave owns exactly one slot (S == nw) the composite record of slot k — values [40][33],
-    // alpha [32], normalised weight [32] — reuses wave k's own staging area, dead by then.
-    const size_t wave_fl = (size_t)V * STAGE_V;
-    float* stage = smem + (size_t)wid * wave_fl;
-    const bool alias = a.alias != 0;
-    const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
-    float* rec0 = alias ? smem : smem + (size_t)nw * wave_fl;
-    const float* tc = tar_cam(f, bi);
     unsigned* dbg = a.dbg; (void)dbg;
 
-    // [COMP_CH][COMP_LD] values, then alpha[32], wn[32] per slot
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one
+    // contiguous band of tiles so vertically adjacent rows hit the same L2.
+    const int chunk = (a.ntiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile >= a.ntiles) return;  // whole workgroup leaves together
+    const int team = LOOP ? 0 : wid / S, k0 = LOOP ? wid : wid - team * S;
+    const int sg = tile * a.teams + team;
+    const bool has_seg = sg < a.nsegs;
+    const int sgc = min(sg, a.nsegs - 1);
+    const int seg = sgc % a.nseg, rr = sgc / a.nseg;
+    const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
+    const int x = seg * 32 + j;
+    const bool inrow = has_seg && x < f.W;
+
+    // LDS: [weights (LDSW)] [per-wave staging V x STAGE_V] [composite records unless aliased].  With one
+    // slot per wave the record of slot k reuses wave k's own staging area, dead by then.
+    float* wl = smem;
+    const size_t wfl = LDSW ? (size_t)MFMA_FLOATS : 0;
+    const size_t wave_fl = (size_t)V * STAGE_V;
+    float* stage = smem + wfl + (size_t)wid * wave_fl;
+    const bool alias = a.alias != 0;
+    const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
+    float* rec_team = alias ? smem + wfl + (size_t)team * S * wave_fl : smem + wfl + (size_t)nw * wave_fl + (size_t)team * S * COMP_REC;
+    const float* tc = tar_cam(f, bi);
+    const float* mfg = a.pw + PW_FP32_FLOATS;
+
+    if (LDSW) {  // copy the weight fragments / tables into LDS; visible after the barrier below
+        const float4* src = (const float4*)mfg;
+        for (int i = threadIdx.x; i < MFMA_FLOATS / 4; i += blockDim.x) ((float4*)wl)[i] = src[i];
+    }
+    STAMP(0);
     if (LOOP) {
-        for (int k = wid; k < S; k += nw)
-            render_slot(f, mf, stage, rec0 + (size_t)k * rec_stride, tc, k, bi, row, x, inrow, lane, j, h, a.dbg, a.skip);
+        if (LDSW) __syncthreads();
+        for (int k = k0; k < S; k += nw) {
+            float* ck = rec_team + (size_t)k * rec_stride;
+            bool act; float z; half8 H1;
+            if (slot_gather(f, stage, ck, tc, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
+                __builtin_amdgcn_wave_barrier();
+                PHASE_FENCE();
+                if (!(a.skip & 8)) slot_mlp(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
+            }
+        }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
-        render_slot(f, mf, stage, rec0 + (size_t)wid * rec_stride, tc, wid, bi, row, x, inrow, lane, j, h, a.dbg, a.skip);
+        float* ck = rec_team + (size_t)k0 * rec_stride;
+        bool act; float z; half8 H1;
+        const bool any = slot_gather(f, stage, ck, tc, k0, bi, row, x, inrow, j, h, a.skip, act, z, H1);
+        STAMP(2);
+        if (LDSW) __syncthreads();
+        else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
+        if (any && !(a.skip & 8)) slot_mlp(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
     }
     STAMP(7);
     __syncthreads();
     STAMP(8);
     // transmittance weights per bundle, normalised   utils.py:35-41
-    if (threadIdx.x < 32) {
+    const int tt = threadIdx.x - team * S * 64;  // thread index inside the team
+    const int tthreads = LOOP ? (int)blockDim.x : S * 64;
+    if (tt < 32) {
         float T = 1.f, sum = 0.f;
         for (int k = 0; k < S; ++k) {
-            float* rk = rec0 + (size_t)k * rec_stride;
-            float al = rk[COMP_ALPHA + threadIdx.x];
+            float* rk = rec_team + (size_t)k * rec_stride;
+            float al = rk[COMP_ALPHA + tt];
             float w = al * T;
             T = T * (1.f - al);
-            rk[COMP_WN + threadIdx.x] = w;
+            rk[COMP_WN + tt] = w;
             sum += w;
         }
         float den = fmaxf(sum, 1e-6f);
         for (int k = 0; k < S; ++k) {
-            float* rk = rec0 + (size_t)k * rec_stride;
-            rk[COMP_WN + threadIdx.x] = rk[COMP_WN + threadIdx.x] / den;
+            float* rk = rec_team + (size_t)k * rec_stride;
+            rk[COMP_WN + tt] = rk[COMP_WN + tt] / den;
         }
     }
     __syncthreads();
+    if (!has_seg) return;
     // weighted sums; the segment's (N_b, 39) rows are one contiguous run in memory   utils.py:109-119
     const int nvalid = min(32, f.W - seg * 32);
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
-    for (int qi = threadIdx.x; qi < nvalid * NOUT; qi += blockDim.x) {
+    for (int qi = tt; qi < nvalid * NOUT; qi += tthreads) {
         int jj = qi / NOUT, c = qi - jj * NOUT;
         float acc = 0.f;
         for (int k = 0; k < S; ++k) {
-            const float* rk = rec0 + (size_t)k * rec_stride;
+            const float* rk = rec_team + (size_t)k * rec_stride;
             acc += rk[c * COMP_LD + jj] * rk[COMP_WN + jj];
         }
         a.bf[b0 * NOUT + qi] = acc;
     }
-    if (threadIdx.x < 64) {
-        int jj = threadIdx.x & 31, which = threadIdx.x >> 5;
+    if (tt < 64) {
+        int jj = tt & 31, which = tt >> 5;
         if (jj < nvalid) {
             float acc = 0.f;
             for (int k = 0; k < S; ++k) {
-                const float* rk = rec0 + (size_t)k * rec_stride;
+                const float* rk = rec_team + (size_t)k * rec_stride;
                 float w = rk[COMP_WN + jj];
                 acc += which ? w : rk[NOUT * COMP_LD + jj] * w;
             }
@@ -753,6 +746,18 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
         }
     }
     STAMP(9);
+}
+
+template <bool LDSW, bool LOOP, int WAVES>
+static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LDSW, LOOP, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_render_fused<LDSW, LOOP, WAVES>), dim3(grid), dim3(64 * nw), lds, st, a);
+    return hipGetLastError();
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
@@ -773,39 +778,50 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.pw = pw;
     a.row_begin = row_begin; a.nrows = row_end - row_begin;
     a.nseg = (fr->W + 31) / 32;
-    a.nblk = fr->B * a.nrows * a.nseg;
+    a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.dbg = g_dbg;
+    a.skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     const int S = cfg->max_num_samples, V = fr->V;
-    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
+    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V, wbytes = sizeof(float) * (size_t)MFMA_FLOATS;
     const size_t lds_max = 160 * 1024;
-    // one wave per slot up to 8 slots when LDS allows; otherwise <= 4 waves that loop over the slots
-    int nw = S <= 8 ? S : 4;
-    a.alias = (per_wave >= sizeof(float) * COMP_REC && !getenv("GDB_FUSED_NO_ALIAS")) ? 1 : 0;
-    size_t fixed = a.alias ? 0 : sizeof(float) * (size_t)S * COMP_REC;
-    if (nw != S || fixed + nw * per_wave > lds_max) {  // looping waves: balanced slot counts, separate composite records
-        a.alias = 0; fixed = sizeof(float) * (size_t)S * COMP_REC;
-        nw = S < 4 ? S : 4;
+    const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
+    // Weights stay in global memory (L2-resident) by default: measured on MI355X, 4 three-wave workgroups
+    // per CU (12 waves) beat every LDS-resident-weights shape (6..9 waves per CU) by 25-30 %.
+    // GDB_FUSED_MODE=lds selects the LDS-resident variant for experiments.
+    const char* mode_env = getenv("GDB_FUSED_MODE");
+    const bool allow_ldsw = mode_env && !strcmp(mode_env, "lds");
+    hipStream_t st = (hipStream_t)stream_;
+    hipError_t e;
+    int teams = 0;
+    if (allow_ldsw && rec_fits && S <= 8) {  // LDS-resident weights, as many segments per workgroup as fit (<= 12 waves)
+        teams = 12 / S;
+        if (getenv("GDB_FUSED_TEAMS")) teams = atoi(getenv("GDB_FUSED_TEAMS"));
+        while (teams > 0 && wbytes + (size_t)teams * S * per_wave > lds_max) --teams;
+        if ((size_t)teams > (size_t)a.nsegs) teams = a.nsegs;
+    }
+    if (teams > 0) {
+        const int nw = teams * S;
+        a.teams = teams; a.alias = 1; a.ntiles = (a.nsegs + teams - 1) / teams;
+        const size_t lds = wbytes + (size_t)nw * per_wave;
+        const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+        if (nw <= 4) e = launch_fused<true, false, 4>(a, grid, nw, lds, st);
+        else if (nw <= 8) e = launch_fused<true, false, 8>(a, grid, nw, lds, st);
+        else e = launch_fused<true, false, 12>(a, grid, nw, lds, st);
+    } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one segment per workgroup, weights from global memory
+        a.teams = 1; a.alias = 1; a.ntiles = a.nsegs;
+        const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+        if (S <= 4) e = launch_fused<false, false, 4>(a, grid, S, (size_t)S * per_wave, st);
+        else e = launch_fused<false, false, 8>(a, grid, S, (size_t)S * per_wave, st);
+    } else {  // more slots than waves fit: waves loop over slots, separate composite records
+        const size_t fixed = sizeof(float) * (size_t)S * COMP_REC;
+        int nw = S < 4 ? S : 4;
         nw = (S + (S + nw - 1) / nw - 1) / ((S + nw - 1) / nw);
         while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
+        const size_t lds = fixed + nw * per_wave;
+        if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
+        a.teams = 1; a.alias = 0; a.ntiles = a.nsegs;
+        e = launch_fused<false, true, 4>(a, (unsigned)((a.ntiles + 7) / 8 * 8), nw, lds, st);
     }
-    size_t lds = fixed + nw * per_wave;
-    if (getenv("GDB_FUSED_BIG_LDS")) lds = lds_max > lds ? (size_t)atoi(getenv("GDB_FUSED_BIG_LDS")) : lds;
-    if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
-    a.lds_floats = (int)(lds / 4);
-    a.skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_fused<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = lds_max;
-    }
-    unsigned grid = (unsigned)((a.nblk + 7) / 8 * 8);
-    if (nw == S && nw <= 4) hipLaunchKernelGGL((k_render_fused<false, 4>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
-    else if (nw == S) hipLaunchKernelGGL((k_render_fused<false, 8>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL((k_render_fused<true, 4>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream_, a);
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
     return GDB_OK;
 }

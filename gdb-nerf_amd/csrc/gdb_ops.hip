@@ -84,23 +84,29 @@ extern "C" int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, 
 // ============================================================================================
 // camera block
 // ============================================================================================
-template <int N>
-__device__ void invert_f64(const double* a, double* out) {  // Gauss-Jordan, partial pivoting
-    double m[N][2 * N];
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) { m[i][j] = a[i * N + j]; m[i][N + j] = (i == j) ? 1.0 : 0.0; }
-    for (int c = 0; c < N; ++c) {
-        int p = c;
-        for (int r = c + 1; r < N; ++r) if (fabs(m[r][c]) > fabs(m[p][c])) p = r;
-        if (p != c) for (int j = 0; j < 2 * N; ++j) { double t = m[c][j]; m[c][j] = m[p][j]; m[p][j] = t; }
-        double inv = 1.0 / m[c][c];
-        for (int j = 0; j < 2 * N; ++j) m[c][j] *= inv;
-        for (int r = 0; r < N; ++r) if (r != c) {
-            double fct = m[r][c];
-            for (int j = 0; j < 2 * N; ++j) m[r][j] -= fct * m[c][j];
-        }
-    }
-    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) out[i * N + j] = m[i][N + N * 0 + j];
+// Closed-form fp64 inverses, fully in registers (a Gauss-Jordan with indexed scratch arrays made this
+// single thread the critical path of k_prepare).  4x4 by 2x2 sub-determinants, 3x3 by cofactors.
+__device__ __forceinline__ void invert4_f64(const double* m, double* o) {
+    double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    double inv = 1.0 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * inv;   o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * inv;
+    o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * inv; o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * inv;
+    o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * inv;  o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * inv;
+    o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * inv; o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * inv;
+    o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * inv;   o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * inv;
+    o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * inv; o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * inv;
+    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * inv; o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * inv;
+    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * inv; o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * inv;
+}
+__device__ __forceinline__ void invert3_f64(const double* m, double* o) {
+    double a = m[4] * m[8] - m[5] * m[7], b = m[5] * m[6] - m[3] * m[8], c = m[3] * m[7] - m[4] * m[6];
+    double inv = 1.0 / (m[0] * a + m[1] * b + m[2] * c);
+    o[0] = a * inv; o[1] = (m[2] * m[7] - m[1] * m[8]) * inv; o[2] = (m[1] * m[5] - m[2] * m[4]) * inv;
+    o[3] = b * inv; o[4] = (m[0] * m[8] - m[2] * m[6]) * inv; o[5] = (m[2] * m[3] - m[0] * m[5]) * inv;
+    o[6] = c * inv; o[7] = (m[1] * m[6] - m[0] * m[7]) * inv; o[8] = (m[0] * m[4] - m[1] * m[3]) * inv;
 }
 
 __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd, const float* __restrict__ tar_exts,
@@ -116,8 +122,8 @@ __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd,
         double E[16], Ei[16], K[9], Ki[9];
         for (int i = 0; i < 16; ++i) E[i] = tar_exts[bi * 16 + i];
         for (int i = 0; i < 9; ++i) K[i] = tar_ints[bi * 9 + i];
-        invert_f64<4>(E, Ei);
-        invert_f64<3>(K, Ki);
+        invert4_f64(E, Ei);
+        invert3_f64(K, Ki);
         for (int i = 0; i < 3; ++i) { tar[T_O + i] = (float)Ei[i * 4 + 3]; tar[T_Z + i] = (float)Ei[i * 4 + 2]; }
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
@@ -139,7 +145,7 @@ __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd,
         const float* Kf = src_ints + ((size_t)bi * V + v) * 9;
         double E[16], Ei[16];
         for (int i = 0; i < 16; ++i) E[i] = Ef[i];
-        invert_f64<4>(E, Ei);
+        invert4_f64(E, Ei);
         for (int i = 0; i < 12; ++i) s[S_E + i] = Ef[i];
         for (int i = 0; i < 9; ++i) { s[S_K + i] = Kf[i]; s[S_KS + i] = (i < 6) ? Kf[i] / (float)b : Kf[i]; }
         for (int i = 0; i < 3; ++i) s[S_C + i] = (float)Ei[i * 4 + 3];
