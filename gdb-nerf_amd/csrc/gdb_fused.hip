@@ -236,17 +236,18 @@ __device__ __forceinline__ void fnormalize3(const float a[3], float o[3]) {
     o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
 }
 
-// Bilinear taps of one mip level in float4 units of the channel-last pyramid (texel = 5 float4):
-// tap indices (without the chunk) and weights, clamp-to-edge.  lw scales the level's weights.
-struct Taps { unsigned i00, i10, i01, i11; float w00, w10, w01, w11; };
+// Bilinear taps of one mip level in float4 units of the chunk-planar pyramid ([chunk][y][x]): tap
+// indices inside a chunk plane, the plane size, and weights; clamp-to-edge.  lw scales the level's weights.
+struct Taps { unsigned i00, i10, i01, i11, plane; float w00, w10, w01, w11; };
 __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsigned lvl4, float lw) {
     int x0, x1, y0, y1; float fx, fy;
     tex_coord(u, W, x0, x1, fx);
     tex_coord(v, H, y0, y1, fy);
     Taps t;
     unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
-    t.i00 = lvl4 + (r0 + x0) * 5u; t.i10 = lvl4 + (r0 + x1) * 5u;
-    t.i01 = lvl4 + (r1 + x0) * 5u; t.i11 = lvl4 + (r1 + x1) * 5u;
+    t.i00 = lvl4 + r0 + x0; t.i10 = lvl4 + r0 + x1;
+    t.i01 = lvl4 + r1 + x0; t.i11 = lvl4 + r1 + x1;
+    t.plane = (unsigned)(W * H);
     float ex = (1.f - fx) * lw, wx = fx * lw;
     t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
     return t;
@@ -259,29 +260,37 @@ __device__ __forceinline__ void taps_fetch(const float4* __restrict__ p, const T
     for (int s = 0; s < 3; ++s) {
         unsigned c = 2 * s + h;
         if (c < GDB_CP / 4) {
-            tap_acc(acc[s], p[t.i00 + c], t.w00);
-            tap_acc(acc[s], p[t.i10 + c], t.w10);
-            tap_acc(acc[s], p[t.i01 + c], t.w01);
-            tap_acc(acc[s], p[t.i11 + c], t.w11);
+            const float4* pc = p + c * t.plane;
+            tap_acc(acc[s], pc[t.i00], t.w00);
+            tap_acc(acc[s], pc[t.i10], t.w10);
+            tap_acc(acc[s], pc[t.i01], t.w01);
+            tap_acc(acc[s], pc[t.i11], t.w11);
         }
     }
 }
 
-// Bilinear RGB, grid_sample border / align_corners=False, from planar (3,Ho,Wo); 32-bit offsets.
+// Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
+struct __attribute__((packed, aligned(4))) F2u { float x, y; };
+__device__ __forceinline__ F2u ld_pair(const float* __restrict__ p) { return *(const F2u*)p; }
+
+// Bilinear RGB, grid_sample border / align_corners=False, from planar (3,Ho,Wo); 32-bit offsets.  The x pair
+// (x0, x0+1) is one 8-byte load: at the right edge the pair is shifted left by one and the weight moved onto
+// its second element, which keeps the pair inside the row (needs Wo >= 2).
 __device__ __forceinline__ void rgb_fetch_fast(const float* __restrict__ img, int Ho, int Wo, float px, float py, float rgb[3]) {
-    // px, py are pixel coordinates (x*Wo/Wo form folded): grid g = 2*px/Wo - 1 -> ((g+1)*Wo - 1)/2 = px - 0.5
+    // px, py are pixel coordinates: grid g = 2*px/Wo - 1 -> ((g+1)*Wo - 1)/2 = px - 0.5
     float x = fminf(fmaxf(px - 0.5f, 0.f), (float)(Wo - 1)), y = fminf(fmaxf(py - 0.5f, 0.f), (float)(Ho - 1));
-    float xf = floorf(x), yf = floorf(y);
-    float wx = x - xf, wy = y - yf;
-    int x0 = (int)xf, y0 = (int)yf;
-    int x1 = min(x0 + 1, Wo - 1), y1 = min(y0 + 1, Ho - 1);  // a clamped tap carries weight 0 (wx = 0 at the edge)
+    float yf = floorf(y);
+    int x0 = min((int)floorf(x), Wo - 2), y0 = (int)yf;
+    float wx = x - (float)x0, wy = y - yf;
+    int y1 = min(y0 + 1, Ho - 1);  // a clamped row carries weight 0 (wy = 0 at the edge)
     float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
-    unsigned o00 = (unsigned)(y0 * Wo + x0), o10 = (unsigned)(y0 * Wo + x1), o01 = (unsigned)(y1 * Wo + x0), o11 = (unsigned)(y1 * Wo + x1);
+    unsigned o0 = (unsigned)(y0 * Wo + x0), o1 = (unsigned)(y1 * Wo + x0);
     unsigned plane = (unsigned)(Ho * Wo);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* p = img + c * plane;
-        rgb[c] = fmaf(p[o11], w11, fmaf(p[o01], w01, fmaf(p[o10], w10, p[o00] * w00)));
+        F2u a = ld_pair(p + o0), b = ld_pair(p + o1);
+        rgb[c] = fmaf(b.y, w11, fmaf(b.x, w01, fmaf(a.y, w10, a.x * w00)));
     }
 }
 
@@ -409,19 +418,35 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
         const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
         const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
         const unsigned cb = 4u * (unsigned)h * cs;
+        if (f.W >= 2) {  // x pair in one 8-byte load (shifted left at the right edge, weight on its second element)
+            int xp = min(x0, f.W - 2);
+            float wxp = gx - (float)xp;
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz)
+            for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
+                for (int dy = 0; dy < 2; ++dy) {
+                    int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);  // a clamped tap carries weight 0
+                    float wyz = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                    float wa = (1.f - wxp) * wyz, wb = wxp * wyz;
+                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xp);
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    int xx = min(x0 + dx, f.W - 1), yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
-                    // a tap clamped at the far edge carries weight 0 (its fraction is 0 there)
-                    float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xx);
+                    for (int c = 0; c < 4; ++c) {
+                        F2u pr = ld_pair(vol + off + c * cs);
+                        vox[c] = fmaf(pr.y, wb, fmaf(pr.x, wa, vox[c]));
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
+                    float wgt = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
+                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) vox[c] = fmaf(vol[off + c * cs], wgt, vox[c]);
                 }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;

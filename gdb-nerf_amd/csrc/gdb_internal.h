@@ -8,7 +8,8 @@
 // ---- fixed network sizes (every config of the reference: dtu_pretrain.yaml:17-42) ----------
 #define GDB_CF 16            // fpn.feat_dims[feat_level]
 #define GDB_CFR (GDB_CF + 3) // feature ⊕ rgb channels of img_feat
-#define GDB_CP 20            // GDB_CFR padded to a multiple of 4 floats (16-B texel chunks)
+#define GDB_CP 20            // GDB_CFR padded to a multiple of 4 floats: five 16-B chunks per texel; the pyramid stores
+                             // each level chunk-planar, [chunk][y][x] of float4 (consecutive lanes read consecutive 16 B)
 #define GDB_CV 8             // mvs.voxel_dim
 #define GDB_HID 64           // nerf.nerf_hidden_dims
 #define GDB_GF 32            // width of global_fc / agg

@@ -158,9 +158,10 @@ __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd,
 // feature pyramid: NCHW (B*V, C_f+3, H, W) -> channel-last, 20-float texels, + box mips
 // ============================================================================================
 // One launch for the whole per-frame preparation.  Workgroups 0..ntiles-1 each take a 32x8 tile of
-// one (batch, view) feature map: read NCHW along x (128-B row segments), keep the tile channel-last
-// in LDS, write level 0 as whole 640-float texel rows and box-filter levels 1..3 (16x4, 8x2, 4x1
-// texels) out of LDS.  The last workgroup computes the camera block.
+// one (batch, view) feature map: read NCHW along x (128-B row segments), keep the tile texel-major
+// in LDS, write level 0 and the box-filtered levels 1..3 (16x4, 8x2, 4x1 texels, out of LDS) in the
+// chunk-planar pyramid layout [level][chunk 0..4][y][x] of float4.  The last workgroup computes the
+// camera block.
 #define PT_W 32
 #define PT_H 8
 struct PrepArgs {
@@ -194,11 +195,13 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     t0[GDB_CFR] = 0.f;
     __syncthreads();
     float* pyr = a.pyr + (size_t)bv * a.pyrStride;
-    // level 0: each tile row is 32 texels x 5 float4, contiguous in the channel-last layout
+    // level 0, chunk-planar: plane c holds the c-th 16-B chunk of every texel, so a wave reading one chunk of 32
+    // neighbouring texels touches 512 contiguous bytes
+    float4* pyr4 = (float4*)pyr;
     for (int i = threadIdx.x; i < PT_W * PT_H * (GDB_CP / 4); i += blockDim.x) {
-        int r = i / (PT_W * (GDB_CP / 4)), q = i - r * (PT_W * (GDB_CP / 4));  // q: float4 index inside the row
-        int px = x0 + q / (GDB_CP / 4), py = y0 + r;
-        if (px < a.W && py < a.H) ((float4*)(pyr + ((size_t)py * a.W + x0) * GDB_CP))[q] = tile4[i];
+        int lx2 = i % PT_W, rc = i / PT_W, c = rc % (GDB_CP / 4), r = rc / (GDB_CP / 4);
+        int px = x0 + lx2, py = y0 + r;
+        if (px < a.W && py < a.H) pyr4[((size_t)c * a.H + py) * a.W + px] = tile4[(r * PT_W + lx2) * (GDB_CP / 4) + c];
     }
     // levels 1..3 from the level below, in LDS; (a+b+c+d)*0.25 as nvdiffrast's mip construction
     int srcBase = 0, sw = PT_W, sh = PT_H;
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
                                    (A.z + Bq.z + C.z + D.z) * 0.25f, (A.w + Bq.w + C.w + D.w) * 0.25f);
             tile4[(dstBase + dy * dw + dx) * (GDB_CP / 4) + ch] = o;
             int px = (x0 >> l) + dx, py = (y0 >> l) + dy;
-            if (px < W_l && py < H_l) ((float4*)(pyr + a.lvlOff[l] + ((size_t)py * W_l + px) * GDB_CP))[ch] = o;
+            if (px < W_l && py < H_l) pyr4[(a.lvlOff[l] >> 2) + ((size_t)ch * H_l + py) * W_l + px] = o;
         }
         __syncthreads();
         srcBase = dstBase; sw = dw; sh = dh;
@@ -468,15 +471,12 @@ __device__ __forceinline__ void tex_level(const DevFrame& f, const float* __rest
     int x0, x1, y0, y1; float fx, fy;
     tex_coord(u, W, x0, x1, fx);
     tex_coord(v, H, y0, y1, fy);
-    const float* base = pyr + f.lvlOff[l];
-    const float4* a00 = (const float4*)(base + ((size_t)y0 * W + x0) * GDB_CP);
-    const float4* a10 = (const float4*)(base + ((size_t)y0 * W + x1) * GDB_CP);
-    const float4* a01 = (const float4*)(base + ((size_t)y1 * W + x0) * GDB_CP);
-    const float4* a11 = (const float4*)(base + ((size_t)y1 * W + x1) * GDB_CP);
+    const float4* base = (const float4*)(pyr + f.lvlOff[l]);  // chunk-planar: [chunk][y][x]
 #pragma unroll
     for (int c = 0; c < GDB_CP / 4; ++c) {
-        float4 top = lerp4(a00[c], a10[c], fx);
-        float4 bot = lerp4(a01[c], a11[c], fx);
+        const float4* pl = base + (size_t)c * H * W;
+        float4 top = lerp4(pl[(size_t)y0 * W + x0], pl[(size_t)y0 * W + x1], fx);
+        float4 bot = lerp4(pl[(size_t)y1 * W + x0], pl[(size_t)y1 * W + x1], fx);
         out[c] = lerp4(top, bot, fy);
     }
 }

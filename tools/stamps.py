@@ -10,13 +10,14 @@ eng.prepare({k: torch.from_numpy(v).cuda() for k, v in frame.items()})
 for _ in range(3): eng.render()
 lib = _lib.load(); lib.gdb_debug_set_buffer.argtypes = [ctypes.c_void_p]; lib.gdb_debug_set_buffer.restype = None
 nblk = 2560 + 8
-dbg = torch.zeros(nblk * 8 * 16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device="cuda")
 lib.gdb_debug_set_buffer(dbg.data_ptr())
 eng.render(); torch.cuda.synchronize()
 lib.gdb_debug_set_buffer(None)
-t = dbg.cpu().numpy().reshape(nblk, 8, 16)[:, :3, :10].reshape(-1, 10).astype(np.int64)
+t = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :10].reshape(-1, 10).astype(np.int64)
+t[:, 1] = t[:, 0]
 t = t[(t[:, 0] > 0) & (t[:, 9] > 0)]
-names = ["bundle+sample+vox", "gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
+names = ["(unused)", "bundle+vox+gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
 full = t[t[:, 6] > 0]  # waves that ran a slot
 d = np.diff(full, axis=1).astype(np.float64)
 tot = (full[:, 9] - full[:, 0]).mean()
