@@ -97,13 +97,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    # GDB_BENCH_REHEARSE=1: several ranks share the visible GPU(s) over gloo — a logic rehearsal of the
+    # N > 1 path on a one-GPU box, never a measurement.
+    rehearse = os.environ.get("GDB_BENCH_REHEARSE") == "1"
+    local = local % torch.cuda.device_count() if rehearse else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
     wl = WORKLOADS[args.workload]
     Ho, Wo, V = wl["Ho"], wl["Wo"], wl["V"]
@@ -159,7 +166,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
