@@ -198,7 +198,7 @@ __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float v = a[8 * S + i];
-        r[i] = (_Float16)(RELU ? __builtin_amdgcn_fmed3f(v, 0.f, 65504.f) : to_h_range(v));
+        r[i] = (_Float16)(RELU ? __builtin_amdgcn_fmed3f(v, 0.f, 65504.f) : v);  // |v| > 65504 becomes inf, as any f16 conversion
     }
     return r;
 }
@@ -313,11 +313,11 @@ __device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, i
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = st[(ROW_DIR + e) * 32 + j];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t.T0[i] = (_Float16)to_h_range(t.fv[i]);
+    for (int i = 0; i < 8; ++i) t.T0[i] = (_Float16)t.fv[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        t.T1[i] = (_Float16)to_h_range(t.fv[8 + i]);              // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
-        t.T1[4 + i] = (_Float16)(h == 0 ? to_h_range(d[i]) : 0.f);  // dir sits at tv[24..27], owned by half 0
+        t.T1[i] = (_Float16)t.fv[8 + i];                // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
+        t.T1[4 + i] = (_Float16)(h == 0 ? d[i] : 0.f);  // dir sits at tv[24..27], owned by half 0
     }
     return t;
 }
@@ -399,7 +399,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                                             int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
     const int V = f.V;
     Bundle<4> q;
-    load_bundle<4>(f, bi, row, min(x, f.W - 1), q);
+    load_bundle<4, true>(f, bi, row, min(x, f.W - 1), q);
     act = inrow && k < q.count;
     if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
         for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
@@ -407,13 +407,13 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
         return false;
     }
     float dn, ball, xyz[4][3], ctr[3];
-    bundle_sample<4>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
+    bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
     float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
     if (act && !(skip & 4)) {
         float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
         float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
-        float wx = gx - xf, wy = gy - yf, wz = gz - zf;
+        float wy = gy - yf, wz = gz - zf;
         int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
         const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
         const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
@@ -451,7 +451,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 #pragma unroll
     for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)to_h_range(vox[i]);
+    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)vox[i];
     float xyzh[2][3];  // this half's two sub-ray points
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -508,7 +508,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
                 m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
             }
         }
-        float iv = 1.f / (float)(V - 1);
+        float iv = frcp((float)(V - 1));
 #pragma unroll
         for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78

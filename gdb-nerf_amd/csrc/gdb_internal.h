@@ -162,6 +162,12 @@ __device__ __forceinline__ float ball_unit(float disk, float cosv) {
     return disk * cosv / sqrtf(t * t + 1.f);
 }
 
+__device__ __forceinline__ float ball_unit_fast(float disk, float cosv) {
+    float ic = __builtin_amdgcn_rcpf(cosv);
+    float t = __builtin_amdgcn_sqrtf(fmaxf(ic * ic - 1.f, 1e-12f)) - disk;
+    return disk * cosv * __builtin_amdgcn_rsqf(t * t + 1.f);
+}
+
 // Footprint -> mip level.  bundle_sampler.py:343-348
 __device__ __forceinline__ float mip_level(float cx, float cy, float cz, float ball, float src_pixr) {
     float dist = sqrtf(cx * cx + cy * cy + cz * cz);
@@ -209,7 +215,10 @@ struct Bundle {
     int count;
 };
 
-template <int BB>
+// FAST (fused kernel only): divisions become v_rcp multiplies.  The sample count keeps its IEEE division either way.
+template <bool FAST> __device__ __forceinline__ float gdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+
+template <int BB, bool FAST = false>
 __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
     constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
     const float* tc = tar_cam(f, bi);
@@ -223,33 +232,33 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, in
             ray_dir(tc + T_M, x, y, q.d[by * b + bx]);
 #pragma unroll
             for (int i = 0; i < 3; ++i) sum[i] += q.d[by * b + bx][i];
-            su += 2.f * x / (float)f.Wo - 1.f;
-            sv += 2.f * y / (float)f.Ho - 1.f;
+            su += gdiv<FAST>(2.f * x, (float)f.Wo) - 1.f;
+            sv += gdiv<FAST>(2.f * y, (float)f.Ho) - 1.f;
         }
     float md[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { md[i] = sum[i] / (float)BB; q.o[i] = tc[T_O + i]; }
     q.u = su / (float)BB; q.v = sv / (float)BB;
     float nrm = sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
-    float cosv = (md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2]) / nrm;
-    q.unit = ball_unit(tc[T_DISK], cosv);
+    float cosv = gdiv<FAST>(md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2], nrm);
+    q.unit = FAST ? ball_unit_fast(tc[T_DISK], cosv) : ball_unit(tc[T_DISK], cosv);
     size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
     float n0 = f.depth_range[((size_t)bi * 2) * hw + p], f0 = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
     float vn = f.vol_range[((size_t)bi * 2) * hw + p], vf = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
-    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226
+    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226 (IEEE: feeds the sample count)
     q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
     q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
 }
 
 // One sample of a bundle: mid depth, normalised volume depth, sub-ray points, sphere radius.
-template <int BB>
+template <int BB, bool FAST = false>
 __device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB>& q, int k, float& z, float& dnorm,
                                               float xyz[BB][3], float ctr[3], float& ball) {
-    float step = (q.farv - q.nearv) / (float)q.count;
+    float step = gdiv<FAST>(q.farv - q.nearv, (float)q.count);
     float t0 = q.nearv + step * (float)k, t1 = q.nearv + step * (float)(k + 1);  // :183
     z = 0.5f * (t0 + t1);                                                        // :246
-    dnorm = 2.f * (z - q.vnear) / (q.vfar - q.vnear) - 1.f;                      // :247
-    if (f.inv_depth) z = 1.f / z;                                                // :250-251
+    dnorm = gdiv<FAST>(2.f * (z - q.vnear), q.vfar - q.vnear) - 1.f;             // :247
+    if (f.inv_depth) z = gdiv<FAST>(1.f, z);                                     // :250-251
     float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < BB; ++r)
