@@ -8,7 +8,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [per-dispatch values]
-for path in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
+for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     per = defaultdict(float)
     names = {}
     for r in csv.DictReader(open(path)):
