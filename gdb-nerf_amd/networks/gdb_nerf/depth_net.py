@@ -32,6 +32,12 @@ class _AuxStageNerf(nn.Module):
                                    nn.Linear(hid_dim, 1), nn.ReLU(inplace=True))
 
 
+def _use_hip(t: torch.Tensor, enabled: bool) -> bool:
+    """CUDA tensors take the HIP kernels of the "next" rows N2 / N4 (gdb-nerf_amd/costvol.py; loud failure if the
+    library is missing); CPU tensors take the PyTorch formulation below (the CNNs around them are PyTorch too)."""
+    return enabled and t.is_cuda and t.dtype == torch.float32
+
+
 def get_depth_values(near_far: torch.Tensor, num_depth: int, inv_depth: bool) -> torch.Tensor:
     """(B,2,H,W) near/far -> (B,num_depth,H,W) hypotheses, uniform in depth or in disparity (:399-421)."""
     lo, hi = near_far[:, :1], near_far[:, -1:]
@@ -89,6 +95,7 @@ class DepthNet(nn.Module):
         self.ci_scales = list(mvs.ci_scales)
         self.num_depth = list(mvs.num_depth)
         self.inv_depth = list(mvs.inv_depth)
+        self.hip_cost_volume = bool(getattr(mvs, "hip_cost_volume", True))
         # the reference indexes feat_dims by the pyramid level again (depth_net.py:32-37); kept for key/shape parity
         nets = [CostRegNet_small(self.feat_dims[self.vol_levels[0]], mvs.voxel_dim, fpn.base_channels)]
         nets += [CostRegNet(self.feat_dims[self.vol_levels[i]], mvs.voxel_dim, fpn.base_channels) for i in range(1, self.num_stages)]
@@ -110,9 +117,16 @@ class DepthNet(nn.Module):
             K_tar[:, :2, :] *= self.vol_scales[s]
             Hs, Ws = int(H0 * self.vol_scales[s]), int(W0 * self.vol_scales[s])
             hyp = get_depth_values(search, self.num_depth[s], self.inv_depth[s]).expand(-1, -1, Hs, Ws)
-            cost = build_feature_volume(feats, src_exts, K_src, tar_exts, K_tar, hyp, self.inv_depth[s])
-            volume, prob = self.cost_regs[s](cost)
-            depth, search = depth_regression(hyp, prob, self.ci_scales[s], self.inv_depth[s])
+            if _use_hip(feats, self.hip_cost_volume):
+                from ... import costvol
+                hyp = hyp.contiguous()
+                cost = costvol.build_feature_volume(feats, src_exts, K_src, tar_exts, K_tar, hyp, self.inv_depth[s])
+                volume, prob = self.cost_regs[s](cost)
+                depth, search = costvol.depth_regression(hyp, prob, self.ci_scales[s], self.inv_depth[s])
+            else:
+                cost = build_feature_volume(feats, src_exts, K_src, tar_exts, K_tar, hyp, self.inv_depth[s])
+                volume, prob = self.cost_regs[s](cost)
+                depth, search = depth_regression(hyp, prob, self.ci_scales[s], self.inv_depth[s])
             depths.append(depth.squeeze(1))
             ranges.append(search)
             vol_ranges.append(hyp[:, [0, -1]])

@@ -176,6 +176,22 @@ int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const 
                              int32_t precision, float* d_bundle_feat, float* d_depth, float* d_opacity,
                              void* stream);
 
+/* ---- "next" rows: the step just before the hot path ------------------------ */
+/* build_feature_volume, networks/gdb_nerf/depth_net.py:424-476: plane-sweep warp of the source feature maps
+ * d_src_feat (B,V,C,Hs,Ws) onto the target frustum planes d_depth_values (B,D,Ht,Wt) (depth or, with
+ * inv_depth, disparity) + biased variance over views -> d_out (B,C,D,Ht,Wt).  Intrinsics are the
+ * stage-scaled ones the reference passes.  d_proj_ws: B*V*12 floats of scratch. */
+int gdb_build_feature_volume(const float* d_src_feat, const float* d_src_exts, const float* d_src_ints,
+                             const float* d_tar_exts, const float* d_tar_ints, const float* d_depth_values,
+                             int32_t B, int32_t V, int32_t C, int32_t Hs, int32_t Ws, int32_t D, int32_t Ht, int32_t Wt,
+                             int32_t inv_depth, float* d_proj_ws, float* d_out, void* stream);
+
+/* depth_regression, depth_net.py:479-514: d_depth (B,1,H,W) soft-argmax of d_depth_values (B,D,H,W) under
+ * d_depth_prob, d_ci (B,2,H,W) = mean -/+ ci_scale*std clipped to the hypothesis range (both returned as
+ * depths when inv_depth). */
+int gdb_depth_regression(const float* d_depth_values, const float* d_depth_prob, int32_t B, int32_t D, int32_t H, int32_t W,
+                         float ci_scale, int32_t inv_depth, float* d_depth, float* d_ci, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -518,3 +518,88 @@ def psnr(gt: np.ndarray, pred: np.ndarray, mask: np.ndarray | None = None) -> fl
         gt, pred = gt[mask], pred[mask]
     mse = float(np.mean((gt - pred) ** 2))
     return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+# ----------------------------------------------------------------------------------------
+# N2  build_feature_volume                   (depth_net.py:424-476)      [SURVEY §8(f) "next" row]
+# ----------------------------------------------------------------------------------------
+def bilinear_zeros(img: np.ndarray, gx: np.ndarray, gy: np.ndarray) -> np.ndarray:
+    """F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) (depth_net.py:472).
+    img (C,H,W); gx, gy (N,) in normalised coordinates -> (C,N).  Out-of-image taps contribute 0."""
+    C, H, W = img.shape
+    x = (((gx + F32(1)) * F32(W) - F32(1)) / F32(2)).astype(F32)
+    y = (((gy + F32(1)) * F32(H) - F32(1)) / F32(2)).astype(F32)
+    x0f, y0f = np.floor(x), np.floor(y)
+    wx, wy = (x - x0f).astype(F32), (y - y0f).astype(F32)
+    # far-away coordinates (|x| up to 1e9) must not overflow the integer index
+    x0 = np.clip(x0f, -2, W + 1).astype(np.int64)
+    y0 = np.clip(y0f, -2, H + 1).astype(np.int64)
+    out = np.zeros((C, gx.shape[0]), dtype=F32)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = x0 + dx, y0 + dy
+            ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1) & np.isfinite(x) & np.isfinite(y)
+            w = ((wx if dx else F32(1) - wx) * (wy if dy else F32(1) - wy)).astype(F32)
+            v = img[:, np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+            out = out + np.where(ok, v * w, F32(0)).astype(F32)
+    return out
+
+
+def build_feature_volume(src_feat: np.ndarray, src_exts: np.ndarray, src_ints: np.ndarray, tar_exts: np.ndarray,
+                         tar_ints: np.ndarray, depth_values: np.ndarray, inv_depth: bool) -> np.ndarray:
+    """Variance (biased, over source views) of the source features warped onto the target frustum planes.
+    src_feat (B,V,C,Hs,Ws); depth_values (B,D,Ht,Wt); intrinsics already scaled to the stage.
+    depth_net.py:449-453 pixel(target)->pixel(source) maps through the inverse target projection;
+    :456-466 plane sweep; :467-468 perspective divide with z clamped at 1e-6 and normalisation by the
+    source size; :472 bilinear / zeros; :474 torch.var(unbiased=False) over views."""
+    src_feat, depth_values = _f(src_feat), _f(depth_values)
+    B, V, C, Hs, Ws = src_feat.shape
+    D, Ht, Wt = depth_values.shape[1:]
+    depth = (F32(1) / depth_values).astype(F32) if inv_depth else depth_values
+    P_src = np.matmul(_f(src_ints), _f(src_exts)[..., :3, :]).astype(F32)                # (B,V,3,4)
+    P_tar = np.zeros((B, 4, 4), dtype=F32)
+    P_tar[:, :3] = np.matmul(_f(tar_ints), _f(tar_exts)[:, :3, :])
+    P_tar[:, 3, 3] = 1
+    Hm = np.matmul(P_src, np.linalg.inv(P_tar).astype(F32)[:, None]).astype(F32)         # (B,V,3,4)
+    xs, ys = np.meshgrid(np.arange(Wt, dtype=F32) + F32(0.5), np.arange(Ht, dtype=F32) + F32(0.5), indexing="xy")
+    pix = np.stack((xs.ravel(), ys.ravel(), np.ones(Ht * Wt, dtype=F32)), 0)             # (3,Ht*Wt)
+    out = np.empty((B, C, D, Ht, Wt), dtype=F32)
+    for b in range(B):
+        warped = np.empty((V, C, D, Ht * Wt), dtype=F32)
+        for v in range(V):
+            rot = np.matmul(Hm[b, v, :, :3], pix).astype(F32)                            # (3,Ht*Wt)
+            for d in range(D):
+                p = (rot * depth[b, d].reshape(1, -1) + Hm[b, v, :, 3:]).astype(F32)
+                z = np.maximum(p[2], F32(1e-6))
+                gx = (F32(2) * (p[0] / z) / F32(Ws) - F32(1)).astype(F32)
+                gy = (F32(2) * (p[1] / z) / F32(Hs) - F32(1)).astype(F32)
+                warped[v, :, d] = bilinear_zeros(src_feat[b, v], gx, gy)
+        mean = warped.mean(axis=0, dtype=F32)
+        out[b] = ((warped - mean) ** 2).mean(axis=0, dtype=F32).reshape(C, D, Ht, Wt)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# N4  get_depth_values / depth_regression    (depth_net.py:399-421, 479-514)
+# ----------------------------------------------------------------------------------------
+def get_depth_values(near_far: np.ndarray, num_depth: int, inv_depth: bool) -> np.ndarray:
+    """(B,2,H,W) -> (B,num_depth,H,W) hypotheses, uniform in depth or (inv_depth) in disparity."""
+    nf = _f(near_far)
+    lo, hi = nf[:, :1], nf[:, -1:]
+    if inv_depth:
+        lo, hi = (F32(1) / lo).astype(F32), (F32(1) / hi).astype(F32)
+    steps = np.linspace(0.0, 1.0, num_depth, dtype=F32).reshape(1, num_depth, 1, 1)
+    return (lo + (hi - lo) * steps).astype(F32)
+
+
+def depth_regression(depth_values: np.ndarray, depth_prob: np.ndarray, ci_scale: float, inv_depth: bool):
+    """Soft-argmax depth (B,1,H,W) and confidence interval (B,2,H,W) clipped to the hypothesis range."""
+    dv, pr = _f(depth_values), _f(depth_prob)
+    mean = np.sum(pr * dv, axis=1, keepdims=True, dtype=F32)
+    var = np.sum(pr * (dv - mean) ** 2, axis=1, keepdims=True, dtype=F32)
+    half = (F32(ci_scale) * np.sqrt(np.maximum(var, F32(1e-12)))).astype(F32)
+    first, last = dv[:, :1], dv[:, -1:]
+    if inv_depth:
+        ci = (F32(1) / np.concatenate((np.minimum(mean + half, first), np.maximum(mean - half, last)), axis=1)).astype(F32)
+        return (F32(1) / mean).astype(F32), ci
+    return mean, np.concatenate((np.maximum(mean - half, first), np.minimum(mean + half, last)), axis=1).astype(F32)
