@@ -805,7 +805,11 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.dbg = g_dbg;
-    a.skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
+    // experiment switches, read once: GDB_FUSED_SKIP (timing-only ablation bits), GDB_FUSED_MODE=lds, GDB_FUSED_TEAMS
+    static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
+    static const bool env_lds = getenv("GDB_FUSED_MODE") && !strcmp(getenv("GDB_FUSED_MODE"), "lds");
+    static const int env_teams = getenv("GDB_FUSED_TEAMS") ? atoi(getenv("GDB_FUSED_TEAMS")) : 0;
+    a.skip = env_skip;
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V, wbytes = sizeof(float) * (size_t)MFMA_FLOATS;
     const size_t lds_max = 160 * 1024;
@@ -813,14 +817,13 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     // Weights stay in global memory (L2-resident) by default: measured on MI355X, 4 three-wave workgroups
     // per CU (12 waves) beat every LDS-resident-weights shape (6..9 waves per CU) by 25-30 %.
     // GDB_FUSED_MODE=lds selects the LDS-resident variant for experiments.
-    const char* mode_env = getenv("GDB_FUSED_MODE");
-    const bool allow_ldsw = mode_env && !strcmp(mode_env, "lds");
+    const bool allow_ldsw = env_lds;
     hipStream_t st = (hipStream_t)stream_;
     hipError_t e;
     int teams = 0;
     if (allow_ldsw && rec_fits && S <= 8) {  // LDS-resident weights, as many segments per workgroup as fit (<= 12 waves)
         teams = 12 / S;
-        if (getenv("GDB_FUSED_TEAMS")) teams = atoi(getenv("GDB_FUSED_TEAMS"));
+        if (env_teams > 0) teams = env_teams;
         while (teams > 0 && wbytes + (size_t)teams * S * per_wave > lds_max) --teams;
         if ((size_t)teams > (size_t)a.nsegs) teams = a.nsegs;
     }

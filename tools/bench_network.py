@@ -1,0 +1,27 @@
+"""t_frame: whole Network.forward (CNNs on PyTorch-ROCm + hot path on the HIP library) at DTU eval 512x640, 3 source
+views, random-init weights, the reference's timing protocol (run.py:56-73: synchronise, wall clock, drop the first
+iteration, FPS = 1 / mean).  Prints a JSON object; hot_path in {fused, mirrors}, hip_cost_volume on/off."""
+import json, os, sys, time, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from gdb_nerf_amd import synthetic
+from gdb_nerf_amd.configs import make_cfg
+from gdb_nerf_amd.networks import make_network
+
+fr = synthetic.make_frame(512, 640, V=3, seed=0)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
+         "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
+res = {}
+for name, opts in {"fused + hip cost volume": [], "fused, torch cost volume": ["mvs.hip_cost_volume", "False"],
+                   "operator mirrors + hip cost volume": ["nerf.hot_path", "mirrors"]}.items():
+    torch.manual_seed(0)
+    net = make_network(make_cfg("configs/dtu_eval.yaml", opts)).eval().cuda()
+    times = []
+    with torch.no_grad():
+        for i in range(12):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ret, _, _ = net(batch)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.mean(times[2:]))
+    res[name] = {"ms_per_frame": round(ms, 3), "fps": round(1e3 / ms, 1), "rays_per_s": round(512 * 640 / ms * 1e3)}
+print(json.dumps(res, indent=1))
