@@ -488,9 +488,15 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 
 // NeRF MLP (nerf.py:58-115) of one slot from its staged views; writes the slot's composite record.
 // `mf` = MFMA section of the packed weights, in global memory or (LDS-resident variant) in LDS.
+// VT > 0: the number of views is a compile-time constant, the view loops unroll and each view's operand
+// fragments (tail T0/T1, g_v) stay in registers across the three view passes; VT = 0: runtime V, fragments are
+// rebuilt from LDS in every pass.
+template <int VT>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
                                          const half8 H1, int lane, int j, int h, unsigned* dbg) {
-    const int V = f.V;
+    const int V = VT > 0 ? VT : f.V;
+    constexpr int NC = VT > 0 ? VT : 1, UNR = VT > 0 ? VT : 1;
+    half8 cT0[NC], cT1[NC], cG0[NC], cG1[NC];  // per-view fragment cache (VT > 0 only)
     f32x16 base;
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
         f32x16 mean, m2;
@@ -498,8 +504,11 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
         const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
         const half8 a_view = load_frag(mf, F_VIEW, lane_o);
+#pragma unroll UNR
         for (int v = 0; v < V; ++v) {
-            f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view, b_view);
+            const Tail tl = load_tail(stage + (size_t)v * STAGE_V, j, h);
+            f32x16 g = view_g(tl, a_view, b_view);
+            if (VT > 0) { cT0[v % NC] = tl.T0; cT1[v % NC] = tl.T1; cG0[v % NC] = acc_frag<0, false>(g); cG1[v % NC] = acc_frag<1, false>(g); }
             float inv = frcp((float)(v + 1));
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -525,15 +534,19 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         f32x16 agg;
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
-        const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
-        const half8 a_view = load_frag(mf, F_VIEW, lane_o);
         const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
         const float b_agg = mf[TS_BAGG];
         float mx = -INFINITY, den = 0.f;
+#pragma unroll UNR
         for (int v = 0; v < V; ++v) {
-            f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view, b_view);
-            f32x16 G = MFMA(a_ga0, (acc_frag<0, false>(g)), base);
-            G = MFMA(a_ga1, (acc_frag<1, false>(g)), G);
+            half8 g0, g1;
+            if (VT > 0) { g0 = cG0[v % NC]; g1 = cG1[v % NC]; }
+            else {
+                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), load_frag(mf, F_VIEW, lane_o), load_tab(mf, TB_VIEW, h_o));
+                g0 = acc_frag<0, false>(g); g1 = acc_frag<1, false>(g);
+            }
+            f32x16 G = MFMA(a_ga0, g0, base);
+            G = MFMA(a_ga1, g1, G);
             float sp = dot16_relu(G, load_tab(mf, TD_AGG, h_o));
             float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
             float mn = fmaxf(mx, sv);
@@ -609,19 +622,22 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     {
         const float b_w2 = mf[TS_BW2];
         float mx = -INFINITY, den = 0.f;
+#pragma unroll UNR
         for (int v = 0; v < V; ++v) {
             LANE_KEYS();
             const float* st = stage + (size_t)v * STAGE_V;
-            const Tail t = load_tail(st, j, h);
+            half8 T0, T1;
+            if (VT > 0) { T0 = cT0[v % NC]; T1 = cT1[v % NC]; }
+            else { const Tail t = load_tail(st, j, h); T0 = t.T0; T1 = t.T1; }
             float up;
             {
-                f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), t.T0, hs0);
-                hv = MFMA(load_frag(mf, F_W0C + 1, lane_o), t.T1, hv);
+                f32x16 hv = MFMA(load_frag(mf, F_W0C + 0, lane_o), T0, hs0);
+                hv = MFMA(load_frag(mf, F_W0C + 1, lane_o), T1, hv);
                 up = dot16_relu(hv, load_tab(mf, TD_W2, h_o));
             }
             {
-                f32x16 hv = MFMA(load_frag(mf, F_W0C + 2, lane_o), t.T0, hs1);
-                hv = MFMA(load_frag(mf, F_W0C + 3, lane_o), t.T1, hv);
+                f32x16 hv = MFMA(load_frag(mf, F_W0C + 2, lane_o), T0, hs1);
+                hv = MFMA(load_frag(mf, F_W0C + 3, lane_o), T1, hv);
                 up += dot16_relu(hv, load_tab(mf, TD_W2 + 32, h_o));
             }
             float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
@@ -661,7 +677,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 
 // Workgroup = `teams` segments x S sample slots (one wave per slot); LOOP: one segment, waves loop
 // over slots.  LDSW: the MFMA section of the weights is copied to LDS once per workgroup and shared.
-template <bool LDSW, bool LOOP, int WAVES>
+template <bool LDSW, bool LOOP, int WAVES, int VT>
 __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 4) ? 2 : 3)) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
@@ -709,7 +725,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
             if (slot_gather(f, stage, ck, tc, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!(a.skip & 8)) slot_mlp(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
+                if (!(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
@@ -719,7 +735,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         STAMP(2);
         if (LDSW) __syncthreads();
         else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
-        if (any && !(a.skip & 8)) slot_mlp(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
+        if (any && !(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
     }
     STAMP(7);
     __syncthreads();
@@ -773,16 +789,23 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     STAMP(9);
 }
 
-template <bool LDSW, bool LOOP, int WAVES>
-static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
+template <bool LDSW, bool LOOP, int WAVES, int VT>
+static hipError_t launch_fused_v(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LDSW, LOOP, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LDSW, LOOP, WAVES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((k_render_fused<LDSW, LOOP, WAVES>), dim3(grid), dim3(64 * nw), lds, st, a);
+    hipLaunchKernelGGL((k_render_fused<LDSW, LOOP, WAVES, VT>), dim3(grid), dim3(64 * nw), lds, st, a);
     return hipGetLastError();
+}
+// The 3-view specialisation (every eval config of the reference) exists for the default global-weights, one-slot-per-wave shapes.
+template <bool LDSW, bool LOOP, int WAVES>
+static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
+    static const bool no_v3 = getenv("GDB_FUSED_NO_V3") != nullptr;
+    if (!LDSW && !LOOP && a.f.V == 3 && !no_v3) return launch_fused_v<LDSW, LOOP, WAVES, 3>(a, grid, nw, lds, st);
+    return launch_fused_v<LDSW, LOOP, WAVES, 0>(a, grid, nw, lds, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
