@@ -60,15 +60,25 @@ __global__ void k_costvol_proj(int B, int V, const float* __restrict__ src_exts,
 struct F2c { float x, y; } __attribute__((packed, aligned(4)));
 
 struct CostVolArgs {
-    int B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt;  // cpt: channels per thread (blockIdx.y = d * groups + group)
+    int B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt, tiles, nblk;  // cpt: channels per thread
     const float* feat; const float* proj; const float* depth_values; float* out;
 };
 
 template <int VT>  // number of source views: the per-view tap state lives in registers
 __global__ void __launch_bounds__(256) k_costvol(CostVolArgs a) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // the (y,x) plane flattened: no ragged-row waste
+    // 1-D grid over (batch, tile of 256 voxels of the flattened (y,x) plane, depth plane, channel group), depth
+    // innermost, remapped so that each XCD (blocks b, b+8, ...) walks one contiguous band: the D planes of a tile
+    // and the neighbouring tiles re-read the same source rows out of that XCD's L2.  (With depth as a grid
+    // dimension the 16 MB of source maps were fetched from HBM ~16x: 383 MB FETCH_SIZE at the 256x320 stage.)
     const int groups = (a.C + a.cpt - 1) / a.cpt;
-    const int d = blockIdx.y / groups, c_begin = (blockIdx.y % groups) * a.cpt, c_end = min(c_begin + a.cpt, a.C), b = blockIdx.z;
+    const int chunk = (a.nblk + 7) >> 3;
+    int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (lb >= a.nblk) return;
+    const int g = lb % groups; lb /= groups;
+    const int d = lb % a.D; lb /= a.D;
+    const int tile = lb % a.tiles, b = lb / a.tiles;
+    const int c_begin = g * a.cpt, c_end = min(c_begin + a.cpt, a.C);
+    const int t = tile * blockDim.x + threadIdx.x;  // the (y,x) plane flattened: no ragged-row waste
     if (t >= a.Ht * a.Wt) return;
     const int y = t / a.Wt, x = t - y * a.Wt;
     const size_t vox = ((size_t)d * a.Ht + y) * a.Wt + x;
@@ -135,7 +145,7 @@ extern "C" int gdb_build_feature_volume(const float* d_src_feat, const float* d_
         return gdb_fail(GDB_E_BADARG, "NULL pointer");
     if (B < 1 || V < 1 || C < 1 || Hs < 1 || Ws < 2 || D < 1 || Ht < 1 || Wt < 1) return gdb_fail(GDB_E_SHAPE, "bad cost-volume shape");
     if (V > GDB_MAX_VIEWS) return gdb_fail(GDB_E_SHAPE, "V=%d exceeds %d views", V, GDB_MAX_VIEWS);
-    if ((size_t)C * Hs * Ws >= ((size_t)1 << 32) || (size_t)D * C > 65535 || B > 65535) return gdb_fail(GDB_E_SHAPE, "cost volume too large for the launch grid");
+    if ((size_t)C * Hs * Ws >= ((size_t)1 << 32)) return gdb_fail(GDB_E_SHAPE, "source feature map too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(k_costvol_proj, dim3((B * V + 63) / 64), dim3(64), 0, st, B, V, d_src_exts, d_src_ints, d_tar_exts, d_tar_ints, d_proj_ws);
     LAUNCH_CHECK("k_costvol_proj");
@@ -143,8 +153,11 @@ extern "C" int gdb_build_feature_volume(const float* d_src_feat, const float* d_
     // 44 / 118 us at the two DTU stage shapes for cpt = 32, 8, 4); GDB_COSTVOL_CPT overrides for experiments
     int cpt = C;
     if (getenv("GDB_COSTVOL_CPT")) cpt = atoi(getenv("GDB_COSTVOL_CPT")) > 0 ? atoi(getenv("GDB_COSTVOL_CPT")) : C;
-    CostVolArgs a{B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt, d_src_feat, d_proj_ws, d_depth_values, d_out};
-    const dim3 grid((Ht * Wt + 255) / 256, D * ((C + cpt - 1) / cpt), B), blk(256);
+    const int tiles = (Ht * Wt + 255) / 256, groups = (C + cpt - 1) / cpt;
+    if ((size_t)B * tiles * D * groups >= ((size_t)1 << 31)) return gdb_fail(GDB_E_SHAPE, "cost volume too large for the launch grid");
+    const int nblk = B * tiles * D * groups;
+    CostVolArgs a{B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt, tiles, nblk, d_src_feat, d_proj_ws, d_depth_values, d_out};
+    const dim3 grid((nblk + 7) / 8 * 8), blk(256);
     switch (V) {
         case 1: hipLaunchKernelGGL(k_costvol<1>, grid, blk, 0, st, a); break;
         case 2: hipLaunchKernelGGL(k_costvol<2>, grid, blk, 0, st, a); break;
