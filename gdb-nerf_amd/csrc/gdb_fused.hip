@@ -44,16 +44,16 @@ enum {
     F_W0A = 17,   // weight.0 columns [0,64) on x: [out tile][x tile][k-step]
     F_W0B = 25,   // weight.0 columns [64,88) on [vox|im]: [out tile][k-step]
     F_W0C = 29,   // weight.0 columns [88,111) on the per-view tail: [out tile][k-step]
-    N_FRAGS = 33
+    F_FHB = 33,   // biases of feat_head / sigma, on the constant-one slot of the [vox | im] operand
+    N_FRAGS = 34
 };
+// Biases ride inside the MFMAs wherever an operand has a spare K slot: that slot of the B operand is set to 1.0
+// and the matching column of the weight fragment holds the bias (view_fc: tail slot 19; global_fc: slot 24 of the
+// variance operand; lr0 / weight.0 / feat_head / sigma: element 4 of the [vox | im] k-step-1 operand).  Only fc,
+// whose 32-wide input has no spare slot, keeps a bias table.
 enum {
-    TB_VIEW = N_FRAGS * 256,  // biases in accumulator layout [h][16]
-    TB_GLOB = TB_VIEW + 32,
-    TB_FC = TB_GLOB + 32,
-    TB_LR0 = TB_FC + 32,      // [out tile][h][16]
-    TB_FH = TB_LR0 + 64,
-    TB_W0 = TB_FH + 32,       // [out tile][h][16]
-    TD_AGG = TB_W0 + 64,      // agg_w_fc weights in accumulator layout
+    TB_FC = N_FRAGS * 256,    // fc bias in accumulator layout [h][16]
+    TD_AGG = TB_FC + 32,      // agg_w_fc weights in accumulator layout
     TD_W2 = TD_AGG + 32,      // weight.2 weights [tile][h][16]
     TS_BAGG = TD_W2 + 64,
     TS_BW2 = TS_BAGG + 1,
@@ -71,14 +71,16 @@ struct Packer {
     const float* w;  // fp32 section
     float* out;      // MFMA section
     // kmap(h, i) -> column of W (or -1 for a zero), rows r -> output feature rowmap(r) (or -1)
+    // biasOff >= 0: element (bh, bi) of every row carries that row's bias (the B operand has 1.0 there)
     template <class RowMap, class KMap>
-    void frag(int idx, int wOff, int ld, RowMap rowmap, KMap kmap) {
+    void frag(int idx, int wOff, int ld, RowMap rowmap, KMap kmap, int biasOff = -1, int bh = 0, int bi = 0) {
         _Float16* f = (_Float16*)(out + (size_t)idx * 256);
         for (int l = 0; l < 64; ++l) {
             int r = l & 31, h = l >> 5, orow = rowmap(r);
             for (int i = 0; i < 8; ++i) {
                 int col = kmap(h, i);
                 float v = (orow >= 0 && col >= 0) ? w[wOff + orow * ld + col] : 0.f;
+                if (biasOff >= 0 && h == bh && i == bi) v = orow >= 0 ? w[biasOff + orow] : 0.f;
                 f[l * 8 + i] = (_Float16)v;
             }
         }
@@ -104,9 +106,11 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
     auto tvcol = [&](int s) { return [=](int h, int i) { int k = vrow(s, h, i); return k < GDB_CFR ? k : (k >= 24 && k < 28 ? GDB_CFR + k - 24 : -1); }; };
     auto c19 = [&](int s, int base) { return [=](int h, int i) { int k = vrow(s, h, i); return k < GDB_CFR ? base + k : -1; }; };
     // view_fc reads only dir: W_view column d sits at tv[24+d]
-    p.frag(F_VIEW, PW_VIEW_W, 4, lt(GDB_CFR), [&](int h, int i) { int k = vrow(1, h, i); return (k >= 24 && k < 28) ? k - 24 : -1; });
+    p.frag(F_VIEW, PW_VIEW_W, 4, lt(GDB_CFR), [&](int h, int i) { int k = vrow(1, h, i); return (k >= 24 && k < 28) ? k - 24 : -1; },
+           PW_VIEW_B, 0, 3);  // tv[19] = vrow(1,0,3) carries 1.0
     for (int s = 0; s < 2; ++s) {
-        p.frag(F_GVAR + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, GDB_CFR));
+        if (s == 0) p.frag(F_GVAR + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, GDB_CFR));
+        else p.frag(F_GVAR + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, GDB_CFR), PW_GLOB_B, 0, 4);  // var slot 24 = vrow(1,0,4) carries 1.0
         p.frag(F_GMEAN + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, 2 * GDB_CFR));
         p.frag(F_GA + s, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19(s, 0));
         p.frag(F_FC + s, PW_FC_W, GDB_GF, lt(GDB_IM), [=](int h, int i) { return vrow(s, h, i); });
@@ -117,8 +121,9 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
     };
     for (int ot = 0; ot < 2; ++ot)
         for (int s = 0; s < 2; ++s) {
-            p.frag(F_LR0 + 2 * ot + s, PW_LR0_W, GDB_HD, tile(ot, GDB_HID), hcol(s, 0));
-            p.frag(F_W0B + 2 * ot + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), hcol(s, GDB_HID));
+            // element 4 of half 0 of the [vox | im] k-step-1 operand carries 1.0
+            p.frag(F_LR0 + 2 * ot + s, PW_LR0_W, GDB_HD, tile(ot, GDB_HID), hcol(s, 0), s == 1 ? PW_LR0_B : -1, 0, 4);
+            p.frag(F_W0B + 2 * ot + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), hcol(s, GDB_HID), s == 1 ? PW_W0_B : -1, 0, 4);
             p.frag(F_W0C + 2 * ot + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID),
                    [&, s](int h, int i) { int c = tvcol(s)(h, i); return c >= 0 ? GDB_HID + GDB_HD + c : -1; });
             for (int xt = 0; xt < 2; ++xt)
@@ -137,19 +142,18 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
                 }
             }
         }
-    p.table(TB_VIEW, PW_VIEW_B, 1, lt(GDB_CFR));
-    p.table(TB_GLOB, PW_GLOB_B, 1, lt(GDB_GF));
     p.table(TB_FC, PW_FC_B, 1, lt(GDB_IM));
-    for (int ot = 0; ot < 2; ++ot) {
-        p.table(TB_LR0 + 32 * ot, PW_LR0_B, 1, tile(ot, GDB_HID));
-        p.table(TB_W0 + 32 * ot, PW_W0_B, 1, tile(ot, GDB_HID));
-        p.table(TD_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
-    }
-    for (int h = 0; h < 2; ++h)
-        for (int r = 0; r < 16; ++r) {
-            int row = acc_row(r, h);
-            out[TB_FH + h * 16 + r] = row < GDB_CV ? fp32[PW_FH_B + row] : (row == GDB_CV ? fp32[PW_SIG_B] : 0.f);
+    for (int ot = 0; ot < 2; ++ot) p.table(TD_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
+    {   // F_FHB: rows 0..7 feat_head bias, row 8 sigma bias, at element 4 of half 0
+        _Float16* f = (_Float16*)(out + (size_t)F_FHB * 256);
+        for (int l = 0; l < 64; ++l) {
+            int r = l & 31, h = l >> 5;
+            for (int i = 0; i < 8; ++i) {
+                float v = (h == 0 && i == 4) ? (r < GDB_CV ? fp32[PW_FH_B + r] : (r == GDB_CV ? fp32[PW_SIG_B] : 0.f)) : 0.f;
+                f[l * 8 + i] = (_Float16)v;
+            }
         }
+    }
     p.table(TD_AGG, PW_AGG_W, 1, lt(GDB_GF));
     out[TS_BAGG] = fp32[PW_AGG_B];
     out[TS_BW2] = fp32[PW_W2_B];
@@ -213,7 +217,7 @@ __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
     return ((const half8*)(mf + (size_t)idx * 256))[lane];
 }
-#define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5
+#define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
 __device__ __forceinline__ float dot16_relu(const f32x16& a, const f32x16& w) {
     float s = 0.f;
 #pragma unroll
@@ -319,12 +323,19 @@ __device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, i
         t.T1[i] = (_Float16)t.fv[8 + i];                // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
         t.T1[4 + i] = (_Float16)(h == 0 ? d[i] : 0.f);  // dir sits at tv[24..27], owned by half 0
     }
+    t.T1[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
     return t;
 }
 
 // g_v = feat ⊕ rgb + ReLU(view_fc(dir)) of one staged view, in accumulator layout   nerf.py:69-71
-__device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view, const f32x16& b_view) {
-    f32x16 g = MFMA(a_view, t.T1, b_view);
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view) {
+    f32x16 g = MFMA(a_view, t.T1, zero16());
 #pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + fmaxf(g[i], 0.f);
 #pragma unroll
@@ -452,6 +463,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
     for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) H1[i] = (_Float16)vox[i];
+    H1[4] = (_Float16)1.f;  // constant one: carries the biases of lr0, weight.0, feat_head and sigma (weights there are zero for half 1)
     float xyzh[2][3];  // this half's two sub-ray points
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -502,12 +514,11 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-        const f32x16 b_view = load_tab(mf, TB_VIEW, h_o);
         const half8 a_view = load_frag(mf, F_VIEW, lane_o);
 #pragma unroll UNR
         for (int v = 0; v < V; ++v) {
             const Tail tl = load_tail(stage + (size_t)v * STAGE_V, j, h);
-            f32x16 g = view_g(tl, a_view, b_view);
+            f32x16 g = view_g(tl, a_view);
             if (VT > 0) { cT0[v % NC] = tl.T0; cT1[v % NC] = tl.T1; cG0[v % NC] = acc_frag<0, false>(g); cG1[v % NC] = acc_frag<1, false>(g); }
             float inv = frcp((float)(v + 1));
 #pragma unroll
@@ -520,9 +531,9 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         float iv = frcp((float)(V - 1));
 #pragma unroll
         for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
+        m2[12] = 1.f;  // spare slot 24 of the variance operand: constant one that carries global_fc's bias
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-        base = load_tab(mf, TB_GLOB, h_o);
-        base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), base);
+        base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), zero16());
         base = MFMA(load_frag(mf, F_GVAR + 1, lane_o), (acc_frag<1, false>(m2)), base);
         base = MFMA(load_frag(mf, F_GMEAN, lane_o), (acc_frag<0, false>(mean)), base);
         base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
@@ -535,6 +546,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
+        const half8 a_view2 = load_frag(mf, F_VIEW, lane_o);
         const f32x16 w_agg = load_tab(mf, TD_AGG, h_o);  // loop-invariant: loaded once per slot, not once per view
         const float b_agg = mf[TS_BAGG];
         float mx = -INFINITY, den = 0.f;
@@ -543,7 +555,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
             half8 g0, g1;
             if (VT > 0) { g0 = cG0[v % NC]; g1 = cG1[v % NC]; }
             else {
-                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), load_frag(mf, F_VIEW, lane_o), load_tab(mf, TB_VIEW, h_o));
+                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view2);
                 g0 = acc_frag<0, false>(g); g1 = acc_frag<1, false>(g);
             }
             f32x16 G = MFMA(a_ga0, g0, base);
@@ -571,19 +583,17 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     STAMP(4);
     half8 X00, X01, X10, X11;
     {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-        f32x16 x0 = load_tab(mf, TB_LR0, h_o);
-        x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, x0);
+        f32x16 x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, zero16());
         x0 = MFMA(load_frag(mf, F_LR0 + 1, lane_o), H1, x0);
         X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
-        f32x16 x1 = load_tab(mf, TB_LR0 + 32, h_o);
-        x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, x1);
+        f32x16 x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, zero16());
         x1 = MFMA(load_frag(mf, F_LR0 + 3, lane_o), H1, x1);
         X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
     }
     PHASE_FENCE();
     float fhv[4], sig;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        f32x16 fh = load_tab(mf, TB_FH, h_o);
+        f32x16 fh = MFMA(load_frag(mf, F_FHB, lane_o), H1, zero16());
         fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
         fh = MFMA(load_frag(mf, F_FH + 1, lane_o), X01, fh);
         fh = MFMA(load_frag(mf, F_FH + 2, lane_o), X10, fh);
@@ -596,8 +606,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
     f32x16 hs0, hs1;
     {   LANE_KEYS();
-        hs0 = load_tab(mf, TB_W0, h_o);
-        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane_o), X00, hs0);
+        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane_o), X00, zero16());
         hs0 = MFMA(load_frag(mf, F_W0A + 1, lane_o), X01, hs0);
         hs0 = MFMA(load_frag(mf, F_W0A + 2, lane_o), X10, hs0);
         hs0 = MFMA(load_frag(mf, F_W0A + 3, lane_o), X11, hs0);
@@ -606,8 +615,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     }
     PHASE_FENCE();
     {   LANE_KEYS();
-        hs1 = load_tab(mf, TB_W0 + 32, h_o);
-        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane_o), X00, hs1);
+        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane_o), X00, zero16());
         hs1 = MFMA(load_frag(mf, F_W0A + 5, lane_o), X01, hs1);
         hs1 = MFMA(load_frag(mf, F_W0A + 6, lane_o), X10, hs1);
         hs1 = MFMA(load_frag(mf, F_W0A + 7, lane_o), X11, hs1);
