@@ -36,10 +36,10 @@ extern "C" int gdb_pack_weights(const GdbConfig* cfg, const float* const t[18], 
                                   GDB_CV * GDB_HID, GDB_CV};
     memset(out, 0, sizeof(float) * ((size_t)PW_FP32_FLOATS + gdb_mfma_section_floats()));
     for (int i = 0; i < 18; ++i) {
-        if (!t[i]) {
-            if (i < 2 && !cfg->viewdir_agg) continue;  // view_fc absent without viewdir_agg (nerf.py:19-23)
-            return gdb_fail(GDB_E_BADARG, "weight tensor %d is NULL", i);
-        }
+        // view_fc does not exist without viewdir_agg (nerf.py:19-23): its slots stay zero, which makes the
+        // fused kernel's ReLU(W_view dir + b) term vanish whatever the caller handed in
+        if (i < 2 && !cfg->viewdir_agg) continue;
+        if (!t[i]) return gdb_fail(GDB_E_BADARG, "weight tensor %d is NULL", i);
         memcpy(out + offs[i], t[i], sizeof(float) * sizes[i]);
     }
     gdb_pack_mfma_section(out, out + PW_FP32_FLOATS);

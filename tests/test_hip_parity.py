@@ -229,6 +229,32 @@ def test_fused_vs_oracle(Ho, Wo, V, B, S, adaptive, inv, scene):
     assert _psnr_delta(npy(bf), obf, Ho // 2, Wo // 2) <= 0.05
 
 
+@pytest.mark.parametrize("Ho,Wo,V,S,adaptive,extra", [
+    (32, 64, 8, 16, False, {}),                          # GDB_MAX_VIEWS x GDB_MAX_SAMPLES
+    (32, 64, 2, 1, False, {}),                           # one sample per bundle, two views
+    (64, 80, 3, 3, True, {"viewdir_agg": False}),        # nerf.py:19-23: no view_fc; state dict still carries one
+    (64, 80, 3, 3, True, {"max_mipmap_level": 0}),       # no mip chain: bilinear on level 0 only
+    (64, 80, 3, 4, True, {"global_num_depth": 8}),       # coarse prior grid -> wide adaptive intervals
+])
+def test_fused_config_corners(Ho, Wo, V, S, adaptive, extra):
+    """Limits of the C ABI (include/gdb_nerf_hip.h GDB_MAX_*) and the config switches the reference exposes
+    (nerf.viewdir_agg, nerf.max_mipmap_level, nerf.global_num_depth), fused kernel vs the oracle."""
+    frame = synthetic.make_frame(Ho, Wo, V=V, scene="dtu", seed=33, src_focal_scale=(1.0, 2.3))
+    w = synthetic.make_nerf_weights(seed=8)
+    with np.errstate(all="ignore"):
+        obf, od, oo = oracle.hot_path(frame, w, max_num_samples=S, is_adaptive=adaptive, **extra)
+    eng = engine_for(frame, w, max_num_samples=S, is_adaptive=adaptive, **extra)
+    bf, depth, opac = eng.render()
+    ubf, ud, uo = eng.render_unfused()
+    e, eu = max_abs(npy(bf), obf), max_abs(npy(ubf), obf)
+    print(f"corner {Ho}x{Wo} V{V} S{S} {extra}: fused err {e:.3e}, fp32 chain err {eu:.3e}")
+    assert eu <= 2e-4
+    assert e <= FUSED_TOL
+    assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max())
+    assert max_abs(npy(opac), oo) <= 1e-5
+    assert _psnr_delta(npy(bf), obf, Ho // 2, Wo // 2) <= 0.05
+
+
 def test_fused_matches_unfused_at_full_size():
     """c2 (BASELINE.json configs[1]) is too big for the oracle in a test; at full size the fused kernel is
     checked against the fp32 operator chain, itself oracle-checked above, plus size-independent properties."""
