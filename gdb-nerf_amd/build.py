@@ -17,7 +17,7 @@ SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
 # the fused fast path lets the compiler contract.
-CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast", "gdb_costvol.hip": "off"}
+CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off"}
 
 
 def _stale() -> bool:

@@ -343,6 +343,26 @@ __device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view) {
     return g;
 }
 
+// View-direction code   bundle_sampler.py:362-367.  Contraction is off here: with a source camera at the target
+// pose td == sd, and the reference's td - sd is exactly 0 (so the code is 0,0,0,1); a fused
+// fma(dd_t, r_t, -dd_s * r_s) would leave the product's rounding error instead, which the normalisation
+// then blows up to a unit vector of noise.
+__device__ __forceinline__ void view_dir_code(const float ctr[3], const float* __restrict__ to, const float* __restrict__ so,
+                                              float dir[4]) {
+#pragma clang fp contract(off)
+    float td[3], sd[3], dd[3], dif[3], dnn[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - to[r];
+    fnormalize3(dd, td);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - so[r];
+    fnormalize3(dd, sd);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
+    fnormalize3(dif, dnn);
+    dir[0] = dnn[0]; dir[1] = dnn[1]; dir[2] = dnn[2]; dir[3] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2];
+}
+
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
@@ -390,18 +410,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
         taps_fetch(pyr, t, h, feat);
     }
-    // view-direction code   :362-367
-    float td[3], sd[3], dd[3], dif[3], dnn[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - tc[T_O + r];
-    fnormalize3(dd, td);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - sc[S_C + r];
-    fnormalize3(dd, sd);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dif[r] = td[r] - sd[r];
-    fnormalize3(dif, dnn);
-    dir[0] = dnn[0]; dir[1] = dnn[1]; dir[2] = dnn[2]; dir[3] = td[0] * sd[0] + td[1] * sd[1] + td[2] * sd[2];
+    view_dir_code(ctr, tc + T_O, sc + S_C, dir);
 }
 
 // Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns

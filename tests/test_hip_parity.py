@@ -255,6 +255,43 @@ def test_fused_config_corners(Ho, Wo, V, S, adaptive, extra):
     assert _psnr_delta(npy(bf), obf, Ho // 2, Wo // 2) <= 0.05
 
 
+def _degenerate(kind, f):
+    g = {k: v.copy() for k, v in f.items()}
+    if kind == "faces_away":         # every sample behind source view 1: z clamps at 1e-6, fetches hit the border
+        g["src_exts"][0, 1] = np.diag([-1, 1, -1, 1]).astype(np.float32) @ g["src_exts"][0, 1]
+    elif kind == "src_at_target":    # td - sd is exactly 0 in the reference (bundle_sampler.py:362-367)
+        g["src_exts"][0, 0] = g["tar_ext"][0]
+    elif kind == "duplicate_views":  # zero variance over two of three views
+        for k in ("src_exts", "src_ints", "src_images", "img_feat"):
+            g[k][0, 2] = g[k][0, 1]
+    elif kind == "zero_width_prior":  # depth_range min == max: every interval collapses
+        g["depth_range"][:, 1] = g["depth_range"][:, 0]
+    elif kind == "all_zero":
+        for k in ("src_images", "img_feat", "feat_volume"):
+            g[k][:] = 0
+    return g
+
+
+@pytest.mark.parametrize("kind", ["faces_away", "src_at_target", "duplicate_views", "zero_width_prior", "all_zero"])
+def test_fused_degenerate_geometry(kind):
+    """Degenerate frames the reference handles through its clamps (z >= 1e-6, F.normalize eps, border
+    padding): both device paths must follow the oracle there, and stay finite."""
+    frame = _degenerate(kind, synthetic.make_frame(64, 80, V=3, scene="dtu", seed=5))
+    w = synthetic.make_nerf_weights(seed=8)
+    with np.errstate(all="ignore"):
+        obf, od, oo = oracle.hot_path(frame, w, max_num_samples=3, is_adaptive=True)
+    assert np.isfinite(obf).all()
+    eng = engine_for(frame, w, max_num_samples=3, is_adaptive=True)
+    bf, depth, opac = eng.render()
+    ubf = eng.render_unfused()[0]
+    e, eu = max_abs(npy(bf), obf), max_abs(npy(ubf), obf)
+    print(f"degenerate {kind}: fused err {e:.3e}, fp32 chain err {eu:.3e}")
+    assert np.isfinite(npy(bf)).all() and np.isfinite(npy(ubf)).all()
+    assert eu <= 2e-4
+    assert e <= FUSED_TOL
+    assert max_abs(npy(opac), oo) <= 1e-5
+
+
 def test_fused_matches_unfused_at_full_size():
     """c2 (BASELINE.json configs[1]) is too big for the oracle in a test; at full size the fused kernel is
     checked against the fp32 operator chain, itself oracle-checked above, plus size-independent properties."""
