@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("GDB_HIPCC_EXTRA", "").split(), f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
