@@ -367,7 +367,12 @@ __device__ __forceinline__ void view_dir_code(const float ctr[3], const float* _
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float* __restrict__ tc, float4 feat[3], float dir[4], float rgb[2][3], int skip) {
-    const float* sc = src_cam(f, bi, v);
+    float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: 36 scalar loads, the block lives in SGPRs
+    {
+        const kfloat* scg = kptr(src_cam(f, bi, v));
+#pragma unroll
+        for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
+    }
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
@@ -400,13 +405,17 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
     const float4* pyr = (const float4*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
+    // level offsets as register values: left as f.lvlOff[...] selects, the compiler selects the *address* and
+    // issues a per-lane load from kernarg memory (a full vector-memory round trip for a constant)
+    unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
+    asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
     {
-        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? f.lvlOff[1] : (l0 == 2 ? f.lvlOff[2] : f.lvlOff[3]));
+        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
         Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
         if (!(skip & 2)) taps_fetch(pyr, t, h, feat);
     }
     if (frac > 0.f && !(skip & 2)) {
-        unsigned o1 = l1 == 1 ? f.lvlOff[1] : (l1 == 2 ? f.lvlOff[2] : f.lvlOff[3]);
+        unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
         Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
         taps_fetch(pyr, t, h, feat);
     }
@@ -419,7 +428,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                                             int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
     const int V = f.V;
     Bundle<4> q;
-    load_bundle<4, true>(f, bi, row, min(x, f.W - 1), q);
+    load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q);
     act = inrow && k < q.count;
     if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
         for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
@@ -514,7 +523,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // rebuilt from LDS in every pass.
 template <int VT>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
-                                         const half8 H1, int lane, int j, int h, unsigned* dbg) {
+                                         const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
     const int V = VT > 0 ? VT : f.V;
     constexpr int NC = VT > 0 ? VT : 1, UNR = VT > 0 ? VT : 1;
     half8 cT0[NC], cT1[NC], cG0[NC], cG1[NC];  // per-view fragment cache (VT > 0 only)
@@ -557,7 +566,6 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
         const half8 a_view2 = load_frag(mf, F_VIEW, lane_o);
         const f32x16 w_agg = load_tab(mf, TD_AGG, h_o);  // loop-invariant: loaded once per slot, not once per view
-        const float b_agg = mf[TS_BAGG];
         float mx = -INFINITY, den = 0.f;
 #pragma unroll UNR
         for (int v = 0; v < V; ++v) {
@@ -638,7 +646,6 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
-        const float b_w2 = mf[TS_BW2];
         LANE_KEYS();
         // loop-invariant operands of the per-view pass: loaded once per slot (they were ~a third of all
         // vector-memory traffic when re-issued for every view)
@@ -703,7 +710,9 @@ template <bool LDSW, bool LOOP, int WAVES, int VT>
 __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 4) ? 2 : 3)) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // the wave index is uniform but derived from threadIdx: without readfirstlane everything computed from it (team,
+    // segment, row, batch index, camera and staging pointers) sits in VGPRs and the camera blocks are vector loads
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int V = f.V, S = f.S_max;
     unsigned* dbg = a.dbg; (void)dbg;
@@ -731,8 +740,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     const bool alias = a.alias != 0;
     const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
     float* rec_team = alias ? smem + wfl + (size_t)team * S * wave_fl : smem + wfl + (size_t)nw * wave_fl + (size_t)team * S * COMP_REC;
-    const float* tc = tar_cam(f, bi);
+    float tc[TAR_STRIDE];  // target camera block of this wave's batch entry, in SGPRs
+    {
+        const kfloat* tcg = kptr(tar_cam(f, bi));
+#pragma unroll
+        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
+    }
     const float* mfg = a.pw + PW_FP32_FLOATS;
+    const float b_agg = kptr(mfg)[TS_BAGG], b_w2 = kptr(mfg)[TS_BW2];  // the two scalar biases (agg_w_fc, weight.2)
 
     if (LDSW) {  // copy the weight fragments / tables into LDS; visible after the barrier below
         const float4* src = (const float4*)mfg;
@@ -747,7 +762,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
             if (slot_gather(f, stage, ck, tc, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
+                if (!(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
@@ -757,7 +772,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         STAMP(2);
         if (LDSW) __syncthreads();
         else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
-        if (any && !(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, dbg);
+        if (any && !(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
     }
     STAMP(7);
     __syncthreads();

@@ -218,10 +218,16 @@ struct Bundle {
 // FAST (fused kernel only): divisions become v_rcp multiplies.  The sample count keeps its IEEE division either way.
 template <bool FAST> __device__ __forceinline__ float gdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 
+// Wave-uniform data (camera blocks, bias scalars) read through the constant address space: with a uniform
+// address the load is an s_load into SGPRs (scalar cache, lgkmcnt) instead of a vector-memory round trip.
+// Only for memory no kernel in flight writes (the camera block is written by k_prepare, an earlier launch).
+typedef const float __attribute__((address_space(4))) kfloat;
+__device__ __forceinline__ const kfloat* kptr(const float* p) { return (const kfloat*)p; }
+
+// tc: the target camera block, either in global memory (tar_cam) or a register copy of it.
 template <int BB, bool FAST = false>
-__device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
+__device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<BB>& q) {
     constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
-    const float* tc = tar_cam(f, bi);
     float sum[3] = {0.f, 0.f, 0.f};
     float su = 0.f, sv = 0.f;
 #pragma unroll
@@ -248,6 +254,11 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, in
     if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226 (IEEE: feeds the sample count)
     q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
     q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
+}
+
+template <int BB, bool FAST = false>
+__device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
+    load_bundle<BB, FAST>(f, tar_cam(f, bi), bi, h, w, q);
 }
 
 // One sample of a bundle: mid depth, normalised volume depth, sub-ray points, sphere radius.
