@@ -175,6 +175,13 @@ constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // Per (wave, view) staging in LDS: 35 fp32 rows of 32 bundles — the reference's per-view vector
 // [rgbs 12 | feat ⊕ rgb 19 | dir 4] (bundle_sampler.py:369), one row per channel.
+// Timing-only ablation bits (GDB_FUSED_SKIP; 1 colours, 2 features, 4 volume, 8 MLP) exist only in the diagnostic build
+// -DGDB_DEBUG_SKIP: as runtime branches they split the gather into basic blocks and defeat its load scheduling.
+#ifdef GDB_DEBUG_SKIP
+#define SKIPPED(skip, bit) (((skip) & (bit)) != 0)
+#else
+#define SKIPPED(skip, bit) false
+#endif
 constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND, STAGE_ROWS = NBLEND + 4;
 constexpr int STAGE_V = STAGE_ROWS * 32;     // 1120 floats = 4480 B
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
@@ -259,18 +266,30 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsign
 __device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
     o.x = fmaf(a.x, w, o.x); o.y = fmaf(a.y, w, o.y); o.z = fmaf(a.z, w, o.z); o.w = fmaf(a.w, w, o.w);
 }
-__device__ __forceinline__ void taps_fetch(const float4* __restrict__ p, const Taps& t, int h, float4 acc[3]) {
+// The fetch is split into "issue the loads" and "accumulate" so a view's loads can all be in flight before the
+// first one is consumed (one memory round trip instead of one per block).
+// Chunk ownership: half h takes 16-byte chunks h and 2+h (channels 4h..4h+3, 8+4h..8+4h+3) and the 8-byte half h of
+// chunk 4 (channels 16+2h, 17+2h; channel 19 is padding) — the same unconditional loads in both halves, no branch.
+struct TapData { float4 t[2][4]; float2 u[4]; };
+__device__ __forceinline__ void taps_load(const float4* __restrict__ p, const Taps& t, int h, TapData& d) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        unsigned c = 2 * s + h;
-        if (c < GDB_CP / 4) {
-            const float4* pc = p + c * t.plane;
-            tap_acc(acc[s], pc[t.i00], t.w00);
-            tap_acc(acc[s], pc[t.i10], t.w10);
-            tap_acc(acc[s], pc[t.i01], t.w01);
-            tap_acc(acc[s], pc[t.i11], t.w11);
-        }
+    for (int s = 0; s < 2; ++s) {
+        const float4* pc = p + (2 * s + h) * t.plane;
+        d.t[s][0] = pc[t.i00]; d.t[s][1] = pc[t.i10]; d.t[s][2] = pc[t.i01]; d.t[s][3] = pc[t.i11];
     }
+    const float2* pu = (const float2*)(p + 4 * t.plane) + h;
+    d.u[0] = pu[2 * t.i00]; d.u[1] = pu[2 * t.i10]; d.u[2] = pu[2 * t.i01]; d.u[3] = pu[2 * t.i11];
+}
+__device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4 acc[3]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        tap_acc(acc[s], d.t[s][0], t.w00);
+        tap_acc(acc[s], d.t[s][1], t.w10);
+        tap_acc(acc[s], d.t[s][2], t.w01);
+        tap_acc(acc[s], d.t[s][3], t.w11);
+    }
+    acc[2].x = fmaf(d.u[3].x, t.w11, fmaf(d.u[2].x, t.w01, fmaf(d.u[1].x, t.w10, fmaf(d.u[0].x, t.w00, acc[2].x))));
+    acc[2].y = fmaf(d.u[3].y, t.w11, fmaf(d.u[2].y, t.w01, fmaf(d.u[1].y, t.w10, fmaf(d.u[0].y, t.w00, acc[2].y))));
 }
 
 // Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
@@ -280,22 +299,27 @@ __device__ __forceinline__ F2u ld_pair(const float* __restrict__ p) { return *(c
 // Bilinear RGB, grid_sample border / align_corners=False, from planar (3,Ho,Wo); 32-bit offsets.  The x pair
 // (x0, x0+1) is one 8-byte load: at the right edge the pair is shifted left by one and the weight moved onto
 // its second element, which keeps the pair inside the row (needs Wo >= 2).
-__device__ __forceinline__ void rgb_fetch_fast(const float* __restrict__ img, int Ho, int Wo, float px, float py, float rgb[3]) {
+struct RgbTaps { unsigned o0, o1; float w00, w10, w01, w11; };
+struct RgbData { F2u a[3], b[3]; };
+__device__ __forceinline__ RgbTaps rgb_taps(int Ho, int Wo, float px, float py) {
     // px, py are pixel coordinates: grid g = 2*px/Wo - 1 -> ((g+1)*Wo - 1)/2 = px - 0.5
     float x = fminf(fmaxf(px - 0.5f, 0.f), (float)(Wo - 1)), y = fminf(fmaxf(py - 0.5f, 0.f), (float)(Ho - 1));
     float yf = floorf(y);
     int x0 = min((int)floorf(x), Wo - 2), y0 = (int)yf;
     float wx = x - (float)x0, wy = y - yf;
     int y1 = min(y0 + 1, Ho - 1);  // a clamped row carries weight 0 (wy = 0 at the edge)
-    float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
-    unsigned o0 = (unsigned)(y0 * Wo + x0), o1 = (unsigned)(y1 * Wo + x0);
-    unsigned plane = (unsigned)(Ho * Wo);
+    RgbTaps t;
+    t.w00 = (1.f - wx) * (1.f - wy); t.w10 = wx * (1.f - wy); t.w01 = (1.f - wx) * wy; t.w11 = wx * wy;
+    t.o0 = (unsigned)(y0 * Wo + x0); t.o1 = (unsigned)(y1 * Wo + x0);
+    return t;
+}
+__device__ __forceinline__ void rgb_load(const float* __restrict__ img, unsigned plane, const RgbTaps& t, RgbData& d) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* p = img + c * plane;
-        F2u a = ld_pair(p + o0), b = ld_pair(p + o1);
-        rgb[c] = fmaf(b.y, w11, fmaf(b.x, w01, fmaf(a.y, w10, a.x * w00)));
-    }
+    for (int c = 0; c < 3; ++c) { d.a[c] = ld_pair(img + c * plane + t.o0); d.b[c] = ld_pair(img + c * plane + t.o1); }
+}
+__device__ __forceinline__ void rgb_combine(const RgbTaps& t, const RgbData& d, float rgb[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = fmaf(d.b[c].y, t.w11, fmaf(d.b[c].x, t.w01, fmaf(d.a[c].y, t.w10, d.a[c].x * t.w00)));
 }
 
 extern __shared__ float4 smem4[];
@@ -374,17 +398,8 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
     }
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
-        float cm[3], im[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            cm[r] = fmaf(sc[S_E + 4 * r], xyz[e][0], fmaf(sc[S_E + 4 * r + 1], xyz[e][1], fmaf(sc[S_E + 4 * r + 2], xyz[e][2], sc[S_E + 4 * r + 3])));
-#pragma unroll
-        for (int r = 0; r < 3; ++r) im[r] = fmaf(sc[S_K + 3 * r], cm[0], fmaf(sc[S_K + 3 * r + 1], cm[1], sc[S_K + 3 * r + 2] * cm[2]));
-        float iz = frcp(fmaxf(im[2], 1e-6f));
-        if (!(skip & 1)) rgb_fetch_fast(img, f.Ho, f.Wo, im[0] * iz, im[1] * iz, rgb[e]);
-    }
+    const bool do_rgb = !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
+    // ---- addresses and weights --------------------------------------------------------------------
     // sphere centre in the camera frame: the mean of the sub-ray points maps to the mean of their images   :340
     float cc[3];
 #pragma unroll
@@ -399,8 +414,8 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     float ci[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) ci[r] = fmaf(sc[S_KS + 3 * r], cc[0], fmaf(sc[S_KS + 3 * r + 1], cc[1], sc[S_KS + 3 * r + 2] * cc[2]));
-    float iz = frcp(fmaxf(ci[2], 1e-6f));
-    float tu = ci[0] * iz * frcp((float)f.W), tvv = ci[1] * iz * frcp((float)f.H);   // :351-353
+    float izc = frcp(fmaxf(ci[2], 1e-6f));
+    float tu = ci[0] * izc * frcp((float)f.W), tvv = ci[1] * izc * frcp((float)f.H);   // :351-353
     // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
@@ -409,16 +424,37 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     // issues a per-lane load from kernarg memory (a full vector-memory round trip for a constant)
     unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
     asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
-    {
-        unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
-        Taps t = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
-        if (!(skip & 2)) taps_fetch(pyr, t, h, feat);
+    const unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
+    const Taps t0 = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
+    const bool two = frac > 0.f && do_tex;
+    RgbTaps rt[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
+        float cm[3], im[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            cm[r] = fmaf(sc[S_E + 4 * r], xyz[e][0], fmaf(sc[S_E + 4 * r + 1], xyz[e][1], fmaf(sc[S_E + 4 * r + 2], xyz[e][2], sc[S_E + 4 * r + 3])));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) im[r] = fmaf(sc[S_K + 3 * r], cm[0], fmaf(sc[S_K + 3 * r + 1], cm[1], sc[S_K + 3 * r + 2] * cm[2]));
+        float iz = frcp(fmaxf(im[2], 1e-6f));
+        rt[e] = rgb_taps(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
     }
-    if (frac > 0.f && !(skip & 2)) {
-        unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
-        Taps t = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
-        taps_fetch(pyr, t, h, feat);
+    // ---- issue: level 0 and both sub-rays' colours in flight together -------------------------------
+    TapData d0, d1;
+    RgbData rd[2];
+    if (do_tex) taps_load(pyr, t0, h, d0);
+    const unsigned plane = (unsigned)(f.Ho * f.Wo);
+    if (do_rgb) { rgb_load(img, plane, rt[0], rd[0]); rgb_load(img, plane, rt[1], rd[1]); }
+    // ---- consume level 0, issue level 1, consume the colours under its latency, consume level 1 -------
+    if (do_tex) taps_acc(t0, d0, feat);
+    Taps t1 = t0;
+    if (two) {
+        const unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
+        t1 = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
+        taps_load(pyr, t1, h, d1);
     }
+    if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
+    if (two) taps_acc(t1, d1, feat);
     view_dir_code(ctr, tc + T_O, sc + S_C, dir);
 }
 
@@ -439,7 +475,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
     bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
     float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
-    if (act && !(skip & 4)) {
+    if (act && !SKIPPED(skip, 4)) {
         float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
         float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
         float wy = gy - yf, wz = gz - zf;
@@ -502,12 +538,11 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
             for (int c = 0; c < 3; ++c) st[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
         const float* ff = (const float*)feat;
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int ch = 8 * s + 4 * h + e;
-                if (ch < GDB_CFR) st[(ROW_FEAT + ch) * 32 + j] = ff[4 * s + e];
-            }
+            for (int e = 0; e < 4; ++e) st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
+        st[(ROW_FEAT + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
+        if (h == 0) st[(ROW_FEAT + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
         if (h == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) st[(ROW_DIR + e) * 32 + j] = dir[e];
@@ -762,7 +797,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
             if (slot_gather(f, stage, ck, tc, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+                if (!SKIPPED(a.skip, 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
@@ -772,7 +807,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         STAMP(2);
         if (LDSW) __syncthreads();
         else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
-        if (any && !(a.skip & 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+        if (any && !SKIPPED(a.skip, 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
     }
     STAMP(7);
     __syncthreads();
