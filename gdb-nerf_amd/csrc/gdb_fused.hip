@@ -556,6 +556,10 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // VT > 0: the number of views is a compile-time constant, the view loops unroll and each view's operand
 // fragments (tail T0/T1, g_v) stay in registers across the three view passes; VT = 0: runtime V, fragments are
 // rebuilt from LDS in every pass.
+// Weight fragments are software-pipelined by hand across the phases: every phase first issues the loads of the NEXT
+// phase's fragments (they fly under this phase's MFMAs and VALU work), then computes with fragments loaded one phase
+// earlier.  The fences keep the compiler from moving the loads any further (hoisting all ~45 of them spills), so
+// without this each phase's first MFMA waits a full L2 round trip.
 template <int VT>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
                                          const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
@@ -563,11 +567,17 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     constexpr int NC = VT > 0 ? VT : 1, UNR = VT > 0 ? VT : 1;
     half8 cT0[NC], cT1[NC], cG0[NC], cG1[NC];  // per-view fragment cache (VT > 0 only)
     f32x16 base;
+    half8 a_view, a_ga0, a_ga1;
+    f32x16 w_agg;
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+        a_view = load_frag(mf, F_VIEW, lane_o);
+        const half8 gv0 = load_frag(mf, F_GVAR, lane_o), gv1 = load_frag(mf, F_GVAR + 1, lane_o);
+        const half8 gm0 = load_frag(mf, F_GMEAN, lane_o), gm1 = load_frag(mf, F_GMEAN + 1, lane_o);
+        a_ga0 = load_frag(mf, F_GA, lane_o); a_ga1 = load_frag(mf, F_GA + 1, lane_o);  // next phase
+        w_agg = load_tab(mf, TD_AGG, h_o);
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-        const half8 a_view = load_frag(mf, F_VIEW, lane_o);
 #pragma unroll UNR
         for (int v = 0; v < V; ++v) {
             const Tail tl = load_tail(stage + (size_t)v * STAGE_V, j, h);
@@ -586,28 +596,27 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
         m2[12] = 1.f;  // spare slot 24 of the variance operand: constant one that carries global_fc's bias
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-        base = MFMA(load_frag(mf, F_GVAR, lane_o), (acc_frag<0, false>(m2)), zero16());
-        base = MFMA(load_frag(mf, F_GVAR + 1, lane_o), (acc_frag<1, false>(m2)), base);
-        base = MFMA(load_frag(mf, F_GMEAN, lane_o), (acc_frag<0, false>(mean)), base);
-        base = MFMA(load_frag(mf, F_GMEAN + 1, lane_o), (acc_frag<1, false>(mean)), base);
+        base = MFMA(gv0, (acc_frag<0, false>(m2)), zero16());
+        base = MFMA(gv1, (acc_frag<1, false>(m2)), base);
+        base = MFMA(gm0, (acc_frag<0, false>(mean)), base);
+        base = MFMA(gm1, (acc_frag<1, false>(mean)), base);
     }
     PHASE_FENCE();
     STAMP(3);
-    half8 H0;
+    f32x16 agg, im;
+    half8 fc0, fc1;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-        f32x16 agg;
+        fc0 = load_frag(mf, F_FC, lane_o); fc1 = load_frag(mf, F_FC + 1, lane_o);  // next phase
+        im = load_tab(mf, TB_FC, h_o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
-        const half8 a_ga0 = load_frag(mf, F_GA, lane_o), a_ga1 = load_frag(mf, F_GA + 1, lane_o);
-        const half8 a_view2 = load_frag(mf, F_VIEW, lane_o);
-        const f32x16 w_agg = load_tab(mf, TD_AGG, h_o);  // loop-invariant: loaded once per slot, not once per view
         float mx = -INFINITY, den = 0.f;
 #pragma unroll UNR
         for (int v = 0; v < V; ++v) {
             half8 g0, g1;
             if (VT > 0) { g0 = cG0[v % NC]; g1 = cG1[v % NC]; }
             else {
-                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view2);
+                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view);
                 g0 = acc_frag<0, false>(g); g1 = acc_frag<1, false>(g);
             }
             f32x16 G = MFMA(a_ga0, g0, base);
@@ -624,32 +633,41 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         float r = frcp(den);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] *= r;
-        PHASE_FENCE();
-        const int lane_o2 = opaque(lane), h_o2 = lane_o2 >> 5;
-        f32x16 im = load_tab(mf, TB_FC, h_o2);  // nerf.py:82
-        im = MFMA(load_frag(mf, F_FC, lane_o2), (acc_frag<0, false>(agg)), im);
-        im = MFMA(load_frag(mf, F_FC + 1, lane_o2), (acc_frag<1, false>(agg)), im);
+    }
+    PHASE_FENCE();
+    half8 H0, lr0, lr1, lr2, lr3;
+    {   LANE_KEYS();  // im = fc(agg)   nerf.py:82
+        lr0 = load_frag(mf, F_LR0, lane_o); lr1 = load_frag(mf, F_LR0 + 1, lane_o);  // next phase
+        lr2 = load_frag(mf, F_LR0 + 2, lane_o); lr3 = load_frag(mf, F_LR0 + 3, lane_o);
+        im = MFMA(fc0, (acc_frag<0, false>(agg)), im);
+        im = MFMA(fc1, (acc_frag<1, false>(agg)), im);
         H0 = acc_frag<0, true>(im);
     }
     PHASE_FENCE();
     STAMP(4);
-    half8 X00, X01, X10, X11;
+    half8 X00, X01, X10, X11, fhb, fh0, fh1, fh2, fh3;
     {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-        f32x16 x0 = MFMA(load_frag(mf, F_LR0, lane_o), H0, zero16());
-        x0 = MFMA(load_frag(mf, F_LR0 + 1, lane_o), H1, x0);
+        fhb = load_frag(mf, F_FHB, lane_o); fh0 = load_frag(mf, F_FH, lane_o); fh1 = load_frag(mf, F_FH + 1, lane_o);  // next phase
+        fh2 = load_frag(mf, F_FH + 2, lane_o); fh3 = load_frag(mf, F_FH + 3, lane_o);
+        f32x16 x0 = MFMA(lr0, H0, zero16());
+        x0 = MFMA(lr1, H1, x0);
         X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
-        f32x16 x1 = MFMA(load_frag(mf, F_LR0 + 2, lane_o), H0, zero16());
-        x1 = MFMA(load_frag(mf, F_LR0 + 3, lane_o), H1, x1);
+        f32x16 x1 = MFMA(lr2, H0, zero16());
+        x1 = MFMA(lr3, H1, x1);
         X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
     }
     PHASE_FENCE();
     float fhv[4], sig;
+    half8 wa0, wa1, wa2, wa3, wb0, wb1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        f32x16 fh = MFMA(load_frag(mf, F_FHB, lane_o), H1, zero16());
-        fh = MFMA(load_frag(mf, F_FH, lane_o), X00, fh);
-        fh = MFMA(load_frag(mf, F_FH + 1, lane_o), X01, fh);
-        fh = MFMA(load_frag(mf, F_FH + 2, lane_o), X10, fh);
-        fh = MFMA(load_frag(mf, F_FH + 3, lane_o), X11, fh);
+        wa0 = load_frag(mf, F_W0A + 0, lane_o); wa1 = load_frag(mf, F_W0A + 1, lane_o);  // next phase
+        wa2 = load_frag(mf, F_W0A + 2, lane_o); wa3 = load_frag(mf, F_W0A + 3, lane_o);
+        wb0 = load_frag(mf, F_W0B + 0, lane_o); wb1 = load_frag(mf, F_W0B + 1, lane_o);
+        f32x16 fh = MFMA(fhb, H1, zero16());
+        fh = MFMA(fh0, X00, fh);
+        fh = MFMA(fh1, X01, fh);
+        fh = MFMA(fh2, X10, fh);
+        fh = MFMA(fh3, X11, fh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fhv[i] = fmaxf(fh[i], 0.f);
         sig = fh[4];
@@ -657,22 +675,32 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     PHASE_FENCE();
     // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
     f32x16 hs0, hs1;
+    half8 wc0, wc1, wc2, wc3, wd0, wd1;
     {   LANE_KEYS();
-        hs0 = MFMA(load_frag(mf, F_W0A + 0, lane_o), X00, zero16());
-        hs0 = MFMA(load_frag(mf, F_W0A + 1, lane_o), X01, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0A + 2, lane_o), X10, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0A + 3, lane_o), X11, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0B + 0, lane_o), H0, hs0);
-        hs0 = MFMA(load_frag(mf, F_W0B + 1, lane_o), H1, hs0);
+        wc0 = load_frag(mf, F_W0A + 4, lane_o); wc1 = load_frag(mf, F_W0A + 5, lane_o);  // next phase
+        wc2 = load_frag(mf, F_W0A + 6, lane_o); wc3 = load_frag(mf, F_W0A + 7, lane_o);
+        wd0 = load_frag(mf, F_W0B + 2, lane_o); wd1 = load_frag(mf, F_W0B + 3, lane_o);
+        hs0 = MFMA(wa0, X00, zero16());
+        hs0 = MFMA(wa1, X01, hs0);
+        hs0 = MFMA(wa2, X10, hs0);
+        hs0 = MFMA(wa3, X11, hs0);
+        hs0 = MFMA(wb0, H0, hs0);
+        hs0 = MFMA(wb1, H1, hs0);
     }
     PHASE_FENCE();
+    half8 c00, c01, c10, c11;
+    f32x16 w20, w21;
     {   LANE_KEYS();
-        hs1 = MFMA(load_frag(mf, F_W0A + 4, lane_o), X00, zero16());
-        hs1 = MFMA(load_frag(mf, F_W0A + 5, lane_o), X01, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0A + 6, lane_o), X10, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0A + 7, lane_o), X11, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0B + 2, lane_o), H0, hs1);
-        hs1 = MFMA(load_frag(mf, F_W0B + 3, lane_o), H1, hs1);
+        // operands of the per-view blend pass (next phase; loop-invariant there: loaded once per slot, not per view)
+        c00 = load_frag(mf, F_W0C + 0, lane_o); c01 = load_frag(mf, F_W0C + 1, lane_o);
+        c10 = load_frag(mf, F_W0C + 2, lane_o); c11 = load_frag(mf, F_W0C + 3, lane_o);
+        w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o);
+        hs1 = MFMA(wc0, X00, zero16());
+        hs1 = MFMA(wc1, X01, hs1);
+        hs1 = MFMA(wc2, X10, hs1);
+        hs1 = MFMA(wc3, X11, hs1);
+        hs1 = MFMA(wd0, H0, hs1);
+        hs1 = MFMA(wd1, H1, hs1);
     }
     PHASE_FENCE();
     STAMP(5);
@@ -681,12 +709,6 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
-        LANE_KEYS();
-        // loop-invariant operands of the per-view pass: loaded once per slot (they were ~a third of all
-        // vector-memory traffic when re-issued for every view)
-        const half8 c00 = load_frag(mf, F_W0C + 0, lane_o), c01 = load_frag(mf, F_W0C + 1, lane_o);
-        const half8 c10 = load_frag(mf, F_W0C + 2, lane_o), c11 = load_frag(mf, F_W0C + 3, lane_o);
-        const f32x16 w20 = load_tab(mf, TD_W2, h_o), w21 = load_tab(mf, TD_W2 + 32, h_o);
         float mx = -INFINITY, den = 0.f;
 #pragma unroll UNR
         for (int v = 0; v < V; ++v) {
