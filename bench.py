@@ -87,8 +87,10 @@ def cpu_baseline(wl, frame, weights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)   # one step is ~0.1 ms: 2000 steps = a 0.2 s timed region
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps run for this long before the W warm-up steps, so clocks have ramped (0 = off)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="frames", choices=["frames", "rows"])
@@ -162,12 +164,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp: a fresh process starts at idle clocks and a step is ~0.1 ms, so W warm-up steps alone can end before
+    # the GPU reaches its sustained clock; run untimed steps for a fixed wall time first (not part of W or K)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(20):
+            step(False)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
     sync()
+    ev_stride = max(1, args.steps // 100)  # kernel-duration events on ~100 evenly spaced steps of the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(i % ev_stride == 0)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -205,7 +215,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 fetch/composite, f16 MFMA MLP (f32 accumulate)" if args.path == "fused" else "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
-                   "path": args.path, "shard": args.shard if world > 1 else "none"},
+                   "path": args.path, "shard": args.shard if world > 1 else "none", "prewarm_ms": args.prewarm_ms},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "alg_bytes": ab},
     }
