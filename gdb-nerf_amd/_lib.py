@@ -38,6 +38,7 @@ _SIGNATURES = {
     "gdb_abi_version": (C.c_int, []),
     "gdb_last_error": (C.c_char_p, []),
     "gdb_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
+    "gdb_pyramid_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_packed_weight_floats": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
     "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),

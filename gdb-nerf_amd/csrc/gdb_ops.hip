@@ -81,6 +81,16 @@ extern "C" int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, 
     return GDB_OK;
 }
 
+extern "C" int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
+    if (!out) return gdb_fail(GDB_E_BADARG, "out is NULL");
+    const WsLayout L = ws_layout(*cfg, *shape);
+    out[0] = L.pyrOff; out[1] = L.pyrStride; out[2] = (size_t)L.levels;
+    for (int l = 0; l <= GDB_MAX_MIP; ++l) out[3 + l] = l <= L.levels ? L.lvlOff[l] : 0;
+    return GDB_OK;
+}
+
 // ============================================================================================
 // camera block
 // ============================================================================================
@@ -158,10 +168,12 @@ __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd,
 // feature pyramid: NCHW (B*V, C_f+3, H, W) -> channel-last, 20-float texels, + box mips
 // ============================================================================================
 // One launch for the whole per-frame preparation.  Workgroups 0..ntiles-1 each take a 32x8 tile of
-// one (batch, view) feature map: read NCHW along x (128-B row segments), keep the tile texel-major
-// in LDS, write level 0 and the box-filtered levels 1..3 (16x4, 8x2, 4x1 texels, out of LDS) in the
-// chunk-planar pyramid layout [level][chunk 0..4][y][x] of float4.  The last workgroup computes the
-// camera block.
+// one (batch, view) feature map: read NCHW along x (128-B row segments), write level 0 straight from
+// registers in the chunk-planar pyramid layout [level][chunk 0..4][y][x] of float4 (a wave's 32
+// neighbouring texels of one chunk are 512 contiguous bytes), park the tile in LDS, and after ONE barrier let
+// one thread per (chunk, 4x4 block) build the box-filtered levels: its four level-1 texels and its level-2
+// texel from LDS, level 3 from three lane shuffles.  Each level is the (a+b+c+d)*0.25 of the level below,
+// as nvdiffrast's mip construction.  The last workgroup computes the camera block.
 #define PT_W 32
 #define PT_H 8
 struct PrepArgs {
@@ -174,54 +186,69 @@ struct PrepArgs {
     float* cams;
 };
 
+__device__ __forceinline__ float4 box4(const float4 A, const float4 B, const float4 C, const float4 D) {
+    return make_float4((A.x + B.x + C.x + D.x) * 0.25f, (A.y + B.y + C.y + D.y) * 0.25f,
+                       (A.z + B.z + C.z + D.z) * 0.25f, (A.w + B.w + C.w + D.w) * 0.25f);
+}
+__device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
+}
+
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
-    __shared__ float4 tile4[(PT_W * PT_H + 16 * 4 + 8 * 2 + 4) * (GDB_CP / 4)];
+    __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
     if ((int)blockIdx.x >= a.ntiles) {
         for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
             if (t % (a.V + 1) == 0 || a.src_exts)
                 cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
         return;
     }
-    float* tile = (float*)tile4;
     const int tx = blockIdx.x % a.tilesX, ty = (blockIdx.x / a.tilesX) % a.tilesY, bv = blockIdx.x / (a.tilesX * a.tilesY);
     const int x0 = tx * PT_W, y0 = ty * PT_H;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
     const bool in0 = gx < a.W && gy < a.H;
     const float* src = a.img_feat + (size_t)bv * GDB_CFR * a.H * a.W + (size_t)min(gy, a.H - 1) * a.W + min(gx, a.W - 1);
-    float* t0 = tile + (size_t)threadIdx.x * GDB_CP;
+    float v[GDB_CP];
 #pragma unroll
-    for (int c = 0; c < GDB_CFR; ++c) t0[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
-    t0[GDB_CFR] = 0.f;
-    __syncthreads();
-    float* pyr = a.pyr + (size_t)bv * a.pyrStride;
-    // level 0, chunk-planar: plane c holds the c-th 16-B chunk of every texel, so a wave reading one chunk of 32
-    // neighbouring texels touches 512 contiguous bytes
-    float4* pyr4 = (float4*)pyr;
-    for (int i = threadIdx.x; i < PT_W * PT_H * (GDB_CP / 4); i += blockDim.x) {
-        int lx2 = i % PT_W, rc = i / PT_W, c = rc % (GDB_CP / 4), r = rc / (GDB_CP / 4);
-        int px = x0 + lx2, py = y0 + r;
-        if (px < a.W && py < a.H) pyr4[((size_t)c * a.H + py) * a.W + px] = tile4[(r * PT_W + lx2) * (GDB_CP / 4) + c];
+    for (int c = 0; c < GDB_CFR; ++c) v[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
+    v[GDB_CFR] = 0.f;
+    float4* pyr4 = (float4*)(a.pyr + (size_t)bv * a.pyrStride);
+#pragma unroll
+    for (int c = 0; c < GDB_CP / 4; ++c) {
+        const float4 q = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+        tile4[(c * PT_H + ly) * PT_W + lx] = q;                           // texels outside the map are zero
+        if (in0) pyr4[((size_t)c * a.H + gy) * a.W + gx] = q;
     }
-    // levels 1..3 from the level below, in LDS; (a+b+c+d)*0.25 as nvdiffrast's mip construction
-    int srcBase = 0, sw = PT_W, sh = PT_H;
-    for (int l = 1; l <= a.levels; ++l) {
-        const int dw = sw >> 1, dh = sh >> 1, dstBase = srcBase + sw * sh;
-        const int W_l = a.lvlW[l], H_l = a.lvlH[l];
-        for (int i = threadIdx.x; i < dw * dh * (GDB_CP / 4); i += blockDim.x) {
-            int ch = i % (GDB_CP / 4), p = i / (GDB_CP / 4), dx = p % dw, dy = p / dw;
-            const float4 A = tile4[(srcBase + (2 * dy) * sw + 2 * dx) * (GDB_CP / 4) + ch];
-            const float4 Bq = tile4[(srcBase + (2 * dy) * sw + 2 * dx + 1) * (GDB_CP / 4) + ch];
-            const float4 C = tile4[(srcBase + (2 * dy + 1) * sw + 2 * dx) * (GDB_CP / 4) + ch];
-            const float4 D = tile4[(srcBase + (2 * dy + 1) * sw + 2 * dx + 1) * (GDB_CP / 4) + ch];
-            float4 o = make_float4((A.x + Bq.x + C.x + D.x) * 0.25f, (A.y + Bq.y + C.y + D.y) * 0.25f,
-                                   (A.z + Bq.z + C.z + D.z) * 0.25f, (A.w + Bq.w + C.w + D.w) * 0.25f);
-            tile4[(dstBase + dy * dw + dx) * (GDB_CP / 4) + ch] = o;
-            int px = (x0 >> l) + dx, py = (y0 >> l) + dy;
-            if (px < W_l && py < H_l) pyr4[(a.lvlOff[l] >> 2) + ((size_t)ch * H_l + py) * W_l + px] = o;
+    if (a.levels < 1) return;
+    __syncthreads();
+    // one thread per (chunk, 4x4 block of the tile): 5 x (8 x 2) = 80 threads, 16 consecutive lanes per chunk
+    const int t = threadIdx.x;
+    if (t >= (GDB_CP / 4) * 16) return;
+    const int ch = t >> 4, bx = t & 7, by = (t >> 3) & 1;
+    const float4* T = tile4 + ch * PT_H * PT_W;
+    float4 l1[2][2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int sx = 4 * bx + 2 * i2, sy = 4 * by + 2 * j2;
+            l1[j2][i2] = box4(T[sy * PT_W + sx], T[sy * PT_W + sx + 1], T[(sy + 1) * PT_W + sx], T[(sy + 1) * PT_W + sx + 1]);
+            const int px = (x0 >> 1) + 2 * bx + i2, py = (y0 >> 1) + 2 * by + j2;
+            if (px < a.lvlW[1] && py < a.lvlH[1]) pyr4[(a.lvlOff[1] >> 2) + ((size_t)ch * a.lvlH[1] + py) * a.lvlW[1] + px] = l1[j2][i2];
         }
-        __syncthreads();
-        srcBase = dstBase; sw = dw; sh = dh;
+    if (a.levels < 2) return;
+    const float4 l2 = box4(l1[0][0], l1[0][1], l1[1][0], l1[1][1]);
+    {
+        const int px = (x0 >> 2) + bx, py = (y0 >> 2) + by;
+        if (px < a.lvlW[2] && py < a.lvlH[2]) pyr4[(a.lvlOff[2] >> 2) + ((size_t)ch * a.lvlH[2] + py) * a.lvlW[2] + px] = l2;
+    }
+    if (a.levels < 3) return;
+    // the level-2 neighbours (bx^1, by), (bx, by^1), (bx^1, by^1) sit in lanes t^1, t^8, t^9 of the same 16-lane group
+    const float4 nb = shfl_xor4(l2, 1), nc = shfl_xor4(l2, 8), nd = shfl_xor4(l2, 9);
+    if ((bx & 1) == 0 && by == 0) {
+        const float4 l3 = box4(l2, nb, nc, nd);
+        const int px = (x0 >> 3) + (bx >> 1), py = y0 >> 3;
+        if (px < a.lvlW[3] && py < a.lvlH[3]) pyr4[(a.lvlOff[3] >> 2) + ((size_t)ch * a.lvlH[3] + py) * a.lvlW[3] + px] = l3;
     }
 }
 

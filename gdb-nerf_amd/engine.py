@@ -145,6 +145,22 @@ class HotPathEngine:
         self._frame, self._keep = f, dict(frame)
         _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
 
+    def feature_pyramid(self):
+        """The mip pyramid `prepare` built, as nvdiffrast would hold it: a list over levels of
+        (B, V, H_l, W_l, C_f+3) tensors (copies; the workspace keeps the chunk-planar layout)."""
+        f = self._need_frame()
+        out = (C.c_size_t * 7)()
+        _lib.check(self.lib.gdb_pyramid_layout(C.byref(self.cfg), C.byref(f), out))
+        off, stride, levels = out[0], out[1], out[2]
+        n = f.B * f.V
+        pyr = self._ws[off:off + 4 * stride * n].view(torch.float32).view(n, stride)
+        res = []
+        for l in range(levels + 1):
+            h, w = f.H >> l, f.W >> l
+            lv = pyr[:, out[3 + l]:out[3 + l] + 20 * h * w].reshape(n, 5, h, w, 4)       # [chunk][y][x][4]
+            res.append(lv.permute(0, 2, 3, 1, 4).reshape(f.B, f.V, h, w, 20)[..., :19].contiguous())
+        return res
+
     def _need_frame(self) -> GdbFrame:
         if self._frame is None:
             # bundle_sampler.py:220-221 of the reference

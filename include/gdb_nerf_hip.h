@@ -85,6 +85,14 @@ const char* gdb_last_error(void);
  * channel-last feature pyramid, per-bundle counts/offsets). */
 int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes);
 
+/* Where gdb_prepare() puts the feature pyramid inside the workspace, for callers that want to read it
+ * back (it is what nvdiffrast builds inside texture(): bundle_sampler.py:355-359).  Per (batch, view) the
+ * pyramid is [level][chunk 0..4][y][x] of 16-byte texel chunks (channels 4*chunk .. 4*chunk+3 of the
+ * C_f+3 = 19 channels, channel 19 zero).  out[0] = byte offset of the first pyramid, out[1] = floats per
+ * (batch, view) pyramid, out[2] = number of mip levels built beyond level 0 (stops at the first level with
+ * an odd extent), out[3 + l] = float offset of level l inside one pyramid, l = 0..3. */
+int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]);
+
 /* ---- MLP weights -------------------------------------------------------------------- */
 /* Number of floats in the packed weight buffer for cfg (fp32 section + MFMA-fragment
  * section). */

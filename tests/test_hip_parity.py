@@ -82,6 +82,21 @@ def test_sample_bundle_size_4_vs_golden():
     assert max_abs(npy(s["ball_radii"][:n]), fx["ball_radii"]) <= 1e-5
 
 
+@pytest.mark.parametrize("Ho,Wo,V,B,levels", [(64, 80, 3, 1, 3), (96, 72, 2, 2, 3), (40, 104, 2, 1, 3), (512, 640, 3, 1, 3),
+                                               (64, 80, 2, 1, 1), (64, 80, 2, 1, 0)])
+def test_feature_pyramid_is_bit_exact(Ho, Wo, V, B, levels):
+    """k_prepare's pyramid (layout change + 2x2 box averages) against the oracle's mip construction: exact.
+    (40, 104): W = 52 -> level widths 26, 13: ragged tiles and a chain that stops at the first odd extent."""
+    frame = synthetic.make_frame(Ho, Wo, V=V, B=B, seed=17)
+    eng = engine_for(frame, max_mipmap_level=levels)
+    got = eng.feature_pyramid()
+    for bi in range(B):
+        want = oracle.build_mips(np.transpose(frame["img_feat"][bi], (0, 2, 3, 1)), levels)
+        assert len(got) == len(want)
+        for l, w in enumerate(want):
+            assert np.array_equal(npy(got[l][bi]).view(np.uint32), w.view(np.uint32)), (bi, l)
+
+
 @pytest.mark.parametrize("tag", ["dtu", "nerfinv", "mips"])
 def test_encode_vs_golden(tag):
     """Inputs are the reference's own sample arrays; outputs against the reference's encode."""
