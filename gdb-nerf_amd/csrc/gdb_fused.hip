@@ -460,11 +460,11 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 
 // Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns
 // false (and writes an empty composite record) when no lane has a sample in this slot.
-__device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, int k, int bi,
-                                            int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
+__device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, const float* rng, int k,
+                                            int bi, int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
     const int V = f.V;
     Bundle<4> q;
-    load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q);
+    load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
     act = inrow && k < q.count;
     if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
         for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
@@ -797,6 +797,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     const bool alias = a.alias != 0;
     const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
     float* rec_team = alias ? smem + wfl + (size_t)team * S * wave_fl : smem + wfl + (size_t)nw * wave_fl + (size_t)team * S * COMP_REC;
+    float rng[4];  // this lane's bundle ranges: issued first, the scalar loads below fly under their latency
+    load_ranges(f, bi, row, min(x, f.W - 1), rng);
     float tc[TAR_STRIDE];  // target camera block of this wave's batch entry, in SGPRs
     {
         const kfloat* tcg = kptr(tar_cam(f, bi));
@@ -816,7 +818,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         for (int k = k0; k < S; k += nw) {
             float* ck = rec_team + (size_t)k * rec_stride;
             bool act; float z; half8 H1;
-            if (slot_gather(f, stage, ck, tc, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
+            if (slot_gather(f, stage, ck, tc, rng, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
                 if (!SKIPPED(a.skip, 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
@@ -825,7 +827,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
         float* ck = rec_team + (size_t)k0 * rec_stride;
         bool act; float z; half8 H1;
-        const bool any = slot_gather(f, stage, ck, tc, k0, bi, row, x, inrow, j, h, a.skip, act, z, H1);
+        const bool any = slot_gather(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, H1);
         STAMP(2);
         if (LDSW) __syncthreads();
         else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }

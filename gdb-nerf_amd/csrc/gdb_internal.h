@@ -225,8 +225,17 @@ typedef const float __attribute__((address_space(4))) kfloat;
 __device__ __forceinline__ const kfloat* kptr(const float* p) { return (const kfloat*)p; }
 
 // tc: the target camera block, either in global memory (tar_cam) or a register copy of it.
+// near/far of the depth prior and of the cost volume at bundle (h, w): the only per-lane loads of a bundle
+__device__ __forceinline__ void load_ranges(const DevFrame& f, int bi, int h, int w, float r[4]) {
+    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
+    r[0] = f.depth_range[((size_t)bi * 2) * hw + p]; r[1] = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
+    r[2] = f.vol_range[((size_t)bi * 2) * hw + p];   r[3] = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
+}
+
+// pre: ranges already loaded by the caller (load_ranges), or nullptr
 template <int BB, bool FAST = false>
-__device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<BB>& q) {
+__device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<BB>& q,
+                                            const float* pre = nullptr) {
     constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
     float sum[3] = {0.f, 0.f, 0.f};
     float su = 0.f, sv = 0.f;
@@ -248,9 +257,12 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __re
     float nrm = sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
     float cosv = gdiv<FAST>(md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2], nrm);
     q.unit = FAST ? ball_unit_fast(tc[T_DISK], cosv) : ball_unit(tc[T_DISK], cosv);
-    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
-    float n0 = f.depth_range[((size_t)bi * 2) * hw + p], f0 = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
-    float vn = f.vol_range[((size_t)bi * 2) * hw + p], vf = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
+    float n0 = pre ? pre[0] : 0.f, f0 = pre ? pre[1] : 0.f, vn = pre ? pre[2] : 0.f, vf = pre ? pre[3] : 0.f;
+    if (!pre) {
+        float r[4];
+        load_ranges(f, bi, h, w, r);
+        n0 = r[0]; f0 = r[1]; vn = r[2]; vf = r[3];
+    }
     if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226 (IEEE: feeds the sample count)
     q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
     q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
