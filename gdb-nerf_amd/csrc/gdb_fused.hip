@@ -218,10 +218,33 @@ __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
 // per-lane part goes through an opaque asm once per phase: otherwise hipcc materialises all ~45
 // per-lane addresses at kernel entry (loop-invariant) and spills them.
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+// Load through (wave-uniform base, 32-bit byte offset): the base stays in SGPRs and the offset is one VGPR
+// (global_load ... v_off, s[base:base+1]) instead of a 64-bit per-lane address built for every load — in the
+// per-view gather a fifth of all VALU instructions had been 64-bit address arithmetic.  The entry point checks
+// that every addressed object is smaller than 4 GiB.
+template <typename T>
+__device__ __forceinline__ T ldu(const void* __restrict__ base, unsigned byte_off) {
+    return *(const T*)((const char*)base + byte_off);
+}
+// The same with the uniform part pinned in an SGPR pair: without the pin the compiler folds a constant part of the
+// base into the per-lane offset and is back to 64-bit VGPR address arithmetic (weight fragments: base + idx KiB + lane*16).
+// The pointer is typed as global memory across the pin (an untyped one comes back as a flat pointer: flat_load, 64-bit).
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T ldu_pin(const void* __restrict__ base, unsigned byte_off) {
+    const char GLOBAL_AS* b = (const char GLOBAL_AS*)base;
+    asm volatile("" : "+s"(b));
+    return *(const T GLOBAL_AS*)(b + byte_off);
+}
+// GW: the weight section is in global memory (production) / in LDS (the GDB_FUSED_MODE=lds experiment)
+template <bool GW>
 __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off, int h) {
+    if (GW) return ldu_pin<f32x16>(mf + off, (unsigned)h * 64u);
     return *(const f32x16*)(mf + off + h * 16);
 }
+template <bool GW>
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
+    if (GW) return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
     return ((const half8*)(mf + (size_t)idx * 256))[lane];
 }
 #define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
@@ -247,18 +270,19 @@ __device__ __forceinline__ void fnormalize3(const float a[3], float o[3]) {
     o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
 }
 
-// Bilinear taps of one mip level in float4 units of the chunk-planar pyramid ([chunk][y][x]): tap
-// indices inside a chunk plane, the plane size, and weights; clamp-to-edge.  lw scales the level's weights.
-struct Taps { unsigned i00, i10, i01, i11, plane; float w00, w10, w01, w11; };
-__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsigned lvl4, float lw) {
+// Bilinear taps of one mip level of the chunk-planar pyramid ([chunk][y][x] of 16-byte chunks): byte offsets of
+// the four taps inside chunk plane 0 (level offset lvlB included), the plane size in bytes, and weights;
+// clamp-to-edge.  lw scales the level's weights.
+struct Taps { unsigned o00, o10, o01, o11, planeB; float w00, w10, w01, w11; };  // byte offsets inside chunk plane 0; bytes per chunk plane
+__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsigned lvlB, float lw) {
     int x0, x1, y0, y1; float fx, fy;
     tex_coord(u, W, x0, x1, fx);
     tex_coord(v, H, y0, y1, fy);
     Taps t;
     unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
-    t.i00 = lvl4 + r0 + x0; t.i10 = lvl4 + r0 + x1;
-    t.i01 = lvl4 + r1 + x0; t.i11 = lvl4 + r1 + x1;
-    t.plane = (unsigned)(W * H);
+    t.o00 = lvlB + 16u * (r0 + x0); t.o10 = lvlB + 16u * (r0 + x1);
+    t.o01 = lvlB + 16u * (r1 + x0); t.o11 = lvlB + 16u * (r1 + x1);
+    t.planeB = 16u * (unsigned)(W * H);
     float ex = (1.f - fx) * lw, wx = fx * lw;
     t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
     return t;
@@ -271,14 +295,14 @@ __device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
 // Chunk ownership: half h takes 16-byte chunks h and 2+h (channels 4h..4h+3, 8+4h..8+4h+3) and the 8-byte half h of
 // chunk 4 (channels 16+2h, 17+2h; channel 19 is padding) — the same unconditional loads in both halves, no branch.
 struct TapData { float4 t[2][4]; float2 u[4]; };
-__device__ __forceinline__ void taps_load(const float4* __restrict__ p, const Taps& t, int h, TapData& d) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float4* pc = p + (2 * s + h) * t.plane;
-        d.t[s][0] = pc[t.i00]; d.t[s][1] = pc[t.i10]; d.t[s][2] = pc[t.i01]; d.t[s][3] = pc[t.i11];
-    }
-    const float2* pu = (const float2*)(p + 4 * t.plane) + h;
-    d.u[0] = pu[2 * t.i00]; d.u[1] = pu[2 * t.i10]; d.u[2] = pu[2 * t.i01]; d.u[3] = pu[2 * t.i11];
+__device__ __forceinline__ void taps_load(const void* __restrict__ pyr, const Taps& t, int h, TapData& d) {
+    const unsigned c0 = (unsigned)h * t.planeB, c1 = c0 + 2u * t.planeB, c4 = 4u * t.planeB + 8u * (unsigned)h;
+    d.t[0][0] = ldu<float4>(pyr, t.o00 + c0); d.t[0][1] = ldu<float4>(pyr, t.o10 + c0);
+    d.t[0][2] = ldu<float4>(pyr, t.o01 + c0); d.t[0][3] = ldu<float4>(pyr, t.o11 + c0);
+    d.t[1][0] = ldu<float4>(pyr, t.o00 + c1); d.t[1][1] = ldu<float4>(pyr, t.o10 + c1);
+    d.t[1][2] = ldu<float4>(pyr, t.o01 + c1); d.t[1][3] = ldu<float4>(pyr, t.o11 + c1);
+    d.u[0] = ldu<float2>(pyr, t.o00 + c4); d.u[1] = ldu<float2>(pyr, t.o10 + c4);
+    d.u[2] = ldu<float2>(pyr, t.o01 + c4); d.u[3] = ldu<float2>(pyr, t.o11 + c4);
 }
 __device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4 acc[3]) {
 #pragma unroll
@@ -293,8 +317,8 @@ __device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4
 }
 
 // Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
-struct __attribute__((packed, aligned(4))) F2u { float x, y; };
-__device__ __forceinline__ F2u ld_pair(const float* __restrict__ p) { return *(const F2u*)p; }
+typedef float F2v __attribute__((ext_vector_type(2)));
+typedef F2v F2u __attribute__((aligned(4)));  // a vector type, so it can be loaded through any address space
 
 // Bilinear RGB, grid_sample border / align_corners=False, from planar (3,Ho,Wo); 32-bit offsets.  The x pair
 // (x0, x0+1) is one 8-byte load: at the right edge the pair is shifted left by one and the weight moved onto
@@ -310,12 +334,12 @@ __device__ __forceinline__ RgbTaps rgb_taps(int Ho, int Wo, float px, float py) 
     int y1 = min(y0 + 1, Ho - 1);  // a clamped row carries weight 0 (wy = 0 at the edge)
     RgbTaps t;
     t.w00 = (1.f - wx) * (1.f - wy); t.w10 = wx * (1.f - wy); t.w01 = (1.f - wx) * wy; t.w11 = wx * wy;
-    t.o0 = (unsigned)(y0 * Wo + x0); t.o1 = (unsigned)(y1 * Wo + x0);
+    t.o0 = 4u * (unsigned)(y0 * Wo + x0); t.o1 = 4u * (unsigned)(y1 * Wo + x0);  // byte offsets inside a colour plane
     return t;
 }
 __device__ __forceinline__ void rgb_load(const float* __restrict__ img, unsigned plane, const RgbTaps& t, RgbData& d) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { d.a[c] = ld_pair(img + c * plane + t.o0); d.b[c] = ld_pair(img + c * plane + t.o1); }
+    for (int c = 0; c < 3; ++c) { d.a[c] = ldu<F2u>(img + c * plane, t.o0); d.b[c] = ldu<F2u>(img + c * plane, t.o1); }
 }
 __device__ __forceinline__ void rgb_combine(const RgbTaps& t, const RgbData& d, float rgb[3]) {
 #pragma unroll
@@ -419,13 +443,13 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
-    const float4* pyr = (const float4*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
+    const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
     // level offsets as register values: left as f.lvlOff[...] selects, the compiler selects the *address* and
     // issues a per-lane load from kernarg memory (a full vector-memory round trip for a constant)
     unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
     asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
     const unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
-    const Taps t0 = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 >> 2, 1.f - frac);
+    const Taps t0 = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 << 2, 1.f - frac);
     const bool two = frac > 0.f && do_tex;
     RgbTaps rt[2];
 #pragma unroll
@@ -450,7 +474,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     Taps t1 = t0;
     if (two) {
         const unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
-        t1 = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 >> 2, frac);
+        t1 = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 << 2, frac);
         taps_load(pyr, t1, h, d1);
     }
     if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
@@ -493,10 +517,10 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                     int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);  // a clamped tap carries weight 0
                     float wyz = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
                     float wa = (1.f - wxp) * wyz, wb = wxp * wyz;
-                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W + xp);
+                    unsigned off = 4u * (cb + (unsigned)((zz * f.H + yy) * f.W + xp));
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        F2u pr = ld_pair(vol + off + c * cs);
+                        F2u pr = ldu_pin<F2u>(vol + c * cs, off);
                         vox[c] = fmaf(pr.y, wb, fmaf(pr.x, wa, vox[c]));
                     }
                 }
@@ -507,9 +531,9 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                 for (int dy = 0; dy < 2; ++dy) {
                     int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
                     float wgt = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                    unsigned off = cb + (unsigned)((zz * f.H + yy) * f.W);
+                    unsigned off = 4u * (cb + (unsigned)((zz * f.H + yy) * f.W));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) vox[c] = fmaf(vol[off + c * cs], wgt, vox[c]);
+                    for (int c = 0; c < 4; ++c) vox[c] = fmaf(ldu_pin<float>(vol + c * cs, off), wgt, vox[c]);
                 }
         }
     }
@@ -560,7 +584,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // phase's fragments (they fly under this phase's MFMAs and VALU work), then computes with fragments loaded one phase
 // earlier.  The fences keep the compiler from moving the loads any further (hoisting all ~45 of them spills), so
 // without this each phase's first MFMA waits a full L2 round trip.
-template <int VT>
+template <int VT, bool GW>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
                                          const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
     const int V = VT > 0 ? VT : f.V;
@@ -570,11 +594,11 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     half8 a_view, a_ga0, a_ga1;
     f32x16 w_agg;
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
-        a_view = load_frag(mf, F_VIEW, lane_o);
-        const half8 gv0 = load_frag(mf, F_GVAR, lane_o), gv1 = load_frag(mf, F_GVAR + 1, lane_o);
-        const half8 gm0 = load_frag(mf, F_GMEAN, lane_o), gm1 = load_frag(mf, F_GMEAN + 1, lane_o);
-        a_ga0 = load_frag(mf, F_GA, lane_o); a_ga1 = load_frag(mf, F_GA + 1, lane_o);  // next phase
-        w_agg = load_tab(mf, TD_AGG, h_o);
+        a_view = load_frag<GW>(mf, F_VIEW, lane_o);
+        const half8 gv0 = load_frag<GW>(mf, F_GVAR, lane_o), gv1 = load_frag<GW>(mf, F_GVAR + 1, lane_o);
+        const half8 gm0 = load_frag<GW>(mf, F_GMEAN, lane_o), gm1 = load_frag<GW>(mf, F_GMEAN + 1, lane_o);
+        a_ga0 = load_frag<GW>(mf, F_GA, lane_o); a_ga1 = load_frag<GW>(mf, F_GA + 1, lane_o);  // next phase
+        w_agg = load_tab<GW>(mf, TD_AGG, h_o);
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
@@ -606,8 +630,8 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     f32x16 agg, im;
     half8 fc0, fc1;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-        fc0 = load_frag(mf, F_FC, lane_o); fc1 = load_frag(mf, F_FC + 1, lane_o);  // next phase
-        im = load_tab(mf, TB_FC, h_o);
+        fc0 = load_frag<GW>(mf, F_FC, lane_o); fc1 = load_frag<GW>(mf, F_FC + 1, lane_o);  // next phase
+        im = load_tab<GW>(mf, TB_FC, h_o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         float mx = -INFINITY, den = 0.f;
@@ -637,8 +661,8 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     PHASE_FENCE();
     half8 H0, lr0, lr1, lr2, lr3;
     {   LANE_KEYS();  // im = fc(agg)   nerf.py:82
-        lr0 = load_frag(mf, F_LR0, lane_o); lr1 = load_frag(mf, F_LR0 + 1, lane_o);  // next phase
-        lr2 = load_frag(mf, F_LR0 + 2, lane_o); lr3 = load_frag(mf, F_LR0 + 3, lane_o);
+        lr0 = load_frag<GW>(mf, F_LR0, lane_o); lr1 = load_frag<GW>(mf, F_LR0 + 1, lane_o);  // next phase
+        lr2 = load_frag<GW>(mf, F_LR0 + 2, lane_o); lr3 = load_frag<GW>(mf, F_LR0 + 3, lane_o);
         im = MFMA(fc0, (acc_frag<0, false>(agg)), im);
         im = MFMA(fc1, (acc_frag<1, false>(agg)), im);
         H0 = acc_frag<0, true>(im);
@@ -647,8 +671,8 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     STAMP(4);
     half8 X00, X01, X10, X11, fhb, fh0, fh1, fh2, fh3;
     {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-        fhb = load_frag(mf, F_FHB, lane_o); fh0 = load_frag(mf, F_FH, lane_o); fh1 = load_frag(mf, F_FH + 1, lane_o);  // next phase
-        fh2 = load_frag(mf, F_FH + 2, lane_o); fh3 = load_frag(mf, F_FH + 3, lane_o);
+        fhb = load_frag<GW>(mf, F_FHB, lane_o); fh0 = load_frag<GW>(mf, F_FH, lane_o); fh1 = load_frag<GW>(mf, F_FH + 1, lane_o);  // next phase
+        fh2 = load_frag<GW>(mf, F_FH + 2, lane_o); fh3 = load_frag<GW>(mf, F_FH + 3, lane_o);
         f32x16 x0 = MFMA(lr0, H0, zero16());
         x0 = MFMA(lr1, H1, x0);
         X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
@@ -660,9 +684,9 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     float fhv[4], sig;
     half8 wa0, wa1, wa2, wa3, wb0, wb1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        wa0 = load_frag(mf, F_W0A + 0, lane_o); wa1 = load_frag(mf, F_W0A + 1, lane_o);  // next phase
-        wa2 = load_frag(mf, F_W0A + 2, lane_o); wa3 = load_frag(mf, F_W0A + 3, lane_o);
-        wb0 = load_frag(mf, F_W0B + 0, lane_o); wb1 = load_frag(mf, F_W0B + 1, lane_o);
+        wa0 = load_frag<GW>(mf, F_W0A + 0, lane_o); wa1 = load_frag<GW>(mf, F_W0A + 1, lane_o);  // next phase
+        wa2 = load_frag<GW>(mf, F_W0A + 2, lane_o); wa3 = load_frag<GW>(mf, F_W0A + 3, lane_o);
+        wb0 = load_frag<GW>(mf, F_W0B + 0, lane_o); wb1 = load_frag<GW>(mf, F_W0B + 1, lane_o);
         f32x16 fh = MFMA(fhb, H1, zero16());
         fh = MFMA(fh0, X00, fh);
         fh = MFMA(fh1, X01, fh);
@@ -677,9 +701,9 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     f32x16 hs0, hs1;
     half8 wc0, wc1, wc2, wc3, wd0, wd1;
     {   LANE_KEYS();
-        wc0 = load_frag(mf, F_W0A + 4, lane_o); wc1 = load_frag(mf, F_W0A + 5, lane_o);  // next phase
-        wc2 = load_frag(mf, F_W0A + 6, lane_o); wc3 = load_frag(mf, F_W0A + 7, lane_o);
-        wd0 = load_frag(mf, F_W0B + 2, lane_o); wd1 = load_frag(mf, F_W0B + 3, lane_o);
+        wc0 = load_frag<GW>(mf, F_W0A + 4, lane_o); wc1 = load_frag<GW>(mf, F_W0A + 5, lane_o);  // next phase
+        wc2 = load_frag<GW>(mf, F_W0A + 6, lane_o); wc3 = load_frag<GW>(mf, F_W0A + 7, lane_o);
+        wd0 = load_frag<GW>(mf, F_W0B + 2, lane_o); wd1 = load_frag<GW>(mf, F_W0B + 3, lane_o);
         hs0 = MFMA(wa0, X00, zero16());
         hs0 = MFMA(wa1, X01, hs0);
         hs0 = MFMA(wa2, X10, hs0);
@@ -692,9 +716,9 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     f32x16 w20, w21;
     {   LANE_KEYS();
         // operands of the per-view blend pass (next phase; loop-invariant there: loaded once per slot, not per view)
-        c00 = load_frag(mf, F_W0C + 0, lane_o); c01 = load_frag(mf, F_W0C + 1, lane_o);
-        c10 = load_frag(mf, F_W0C + 2, lane_o); c11 = load_frag(mf, F_W0C + 3, lane_o);
-        w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o);
+        c00 = load_frag<GW>(mf, F_W0C + 0, lane_o); c01 = load_frag<GW>(mf, F_W0C + 1, lane_o);
+        c10 = load_frag<GW>(mf, F_W0C + 2, lane_o); c11 = load_frag<GW>(mf, F_W0C + 3, lane_o);
+        w20 = load_tab<GW>(mf, TD_W2, h_o); w21 = load_tab<GW>(mf, TD_W2 + 32, h_o);
         hs1 = MFMA(wc0, X00, zero16());
         hs1 = MFMA(wc1, X01, hs1);
         hs1 = MFMA(wc2, X10, hs1);
@@ -821,7 +845,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
             if (slot_gather(f, stage, ck, tc, rng, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!SKIPPED(a.skip, 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+                if (!SKIPPED(a.skip, 8)) slot_mlp<VT, !LDSW>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
@@ -831,7 +855,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         STAMP(2);
         if (LDSW) __syncthreads();
         else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
-        if (any && !SKIPPED(a.skip, 8)) slot_mlp<VT>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+        if (any && !SKIPPED(a.skip, 8)) slot_mlp<VT, !LDSW>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
     }
     STAMP(7);
     __syncthreads();
@@ -921,6 +945,10 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
     if (row_begin == row_end) return GDB_OK;
     WsLayout L = ws_layout(*cfg, *fr);
+    // the kernel addresses each of these objects with a 32-bit byte offset from a uniform base
+    const size_t lim = (size_t)1 << 32;
+    if (L.pyrStride * 4 >= lim || (size_t)3 * fr->Ho * fr->Wo * 4 >= lim || (size_t)GDB_CV * fr->D * fr->H * fr->W * 4 >= lim)
+        return gdb_fail(GDB_E_SHAPE, "frame too large for the fused kernel: a per-view pyramid, a source image or a cost volume exceeds 4 GiB");
     FusedArgs a;
     a.f = dev_frame(*cfg, *fr, L, ws);
     a.pw = pw;

@@ -227,9 +227,10 @@ __device__ __forceinline__ const kfloat* kptr(const float* p) { return (const kf
 // tc: the target camera block, either in global memory (tar_cam) or a register copy of it.
 // near/far of the depth prior and of the cost volume at bundle (h, w): the only per-lane loads of a bundle
 __device__ __forceinline__ void load_ranges(const DevFrame& f, int bi, int h, int w, float r[4]) {
-    size_t hw = (size_t)f.H * f.W, p = (size_t)h * f.W + w;
-    r[0] = f.depth_range[((size_t)bi * 2) * hw + p]; r[1] = f.depth_range[((size_t)bi * 2 + 1) * hw + p];
-    r[2] = f.vol_range[((size_t)bi * 2) * hw + p];   r[3] = f.vol_range[((size_t)bi * 2 + 1) * hw + p];
+    size_t hw = (size_t)f.H * f.W;
+    unsigned p = (unsigned)(h * f.W + w);  // 32-bit offset inside one (H, W) plane: with a uniform bi the plane base stays scalar
+    r[0] = (f.depth_range + ((size_t)bi * 2) * hw)[p]; r[1] = (f.depth_range + ((size_t)bi * 2 + 1) * hw)[p];
+    r[2] = (f.vol_range + ((size_t)bi * 2) * hw)[p];   r[3] = (f.vol_range + ((size_t)bi * 2 + 1) * hw)[p];
 }
 
 // pre: ranges already loaded by the caller (load_ranges), or nullptr
