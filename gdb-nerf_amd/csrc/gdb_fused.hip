@@ -207,9 +207,10 @@ template <int S, bool RELU>
 __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
     half8 r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float v = a[8 * S + i];
-        r[i] = (_Float16)(RELU ? __builtin_amdgcn_fmed3f(v, 0.f, 65504.f) : v);  // |v| > 65504 becomes inf, as any f16 conversion
+    for (int i = 0; i < 8; ++i) r[i] = (_Float16)a[8 * S + i];  // |v| > 65504 becomes inf, as any f16 conversion
+    if (RELU) {  // on the packed halves: one v_pk_max_f16 per two values (ReLU commutes with the rounding)
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        r = __builtin_elementwise_max(r, z);
     }
     return r;
 }
@@ -304,16 +305,20 @@ __device__ __forceinline__ void taps_load(const void* __restrict__ pyr, const Ta
     d.u[0] = ldu<float2>(pyr, t.o00 + c4); d.u[1] = ldu<float2>(pyr, t.o10 + c4);
     d.u[2] = ldu<float2>(pyr, t.o01 + c4); d.u[3] = ldu<float2>(pyr, t.o11 + c4);
 }
+// INIT: the accumulators are (re)started by the first tap (acc = a*w, bit-identical to fma(a, w, 0)).
+template <bool INIT>
 __device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4 acc[3]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        tap_acc(acc[s], d.t[s][0], t.w00);
+        if (INIT) acc[s] = make_float4(d.t[s][0].x * t.w00, d.t[s][0].y * t.w00, d.t[s][0].z * t.w00, d.t[s][0].w * t.w00);
+        else tap_acc(acc[s], d.t[s][0], t.w00);
         tap_acc(acc[s], d.t[s][1], t.w10);
         tap_acc(acc[s], d.t[s][2], t.w01);
         tap_acc(acc[s], d.t[s][3], t.w11);
     }
-    acc[2].x = fmaf(d.u[3].x, t.w11, fmaf(d.u[2].x, t.w01, fmaf(d.u[1].x, t.w10, fmaf(d.u[0].x, t.w00, acc[2].x))));
-    acc[2].y = fmaf(d.u[3].y, t.w11, fmaf(d.u[2].y, t.w01, fmaf(d.u[1].y, t.w10, fmaf(d.u[0].y, t.w00, acc[2].y))));
+    const float ax = INIT ? d.u[0].x * t.w00 : fmaf(d.u[0].x, t.w00, acc[2].x), ay = INIT ? d.u[0].y * t.w00 : fmaf(d.u[0].y, t.w00, acc[2].y);
+    acc[2].x = fmaf(d.u[3].x, t.w11, fmaf(d.u[2].x, t.w01, fmaf(d.u[1].x, t.w10, ax)));
+    acc[2].y = fmaf(d.u[3].y, t.w11, fmaf(d.u[2].y, t.w01, fmaf(d.u[1].y, t.w10, ay)));
 }
 
 // Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
@@ -470,7 +475,8 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     const unsigned plane = (unsigned)(f.Ho * f.Wo);
     if (do_rgb) { rgb_load(img, plane, rt[0], rd[0]); rgb_load(img, plane, rt[1], rd[1]); }
     // ---- consume level 0, issue level 1, consume the colours under its latency, consume level 1 -------
-    if (do_tex) taps_acc(t0, d0, feat);
+    if (do_tex) taps_acc<true>(t0, d0, feat);
+    else feat[0] = feat[1] = feat[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     Taps t1 = t0;
     if (two) {
         const unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
@@ -478,7 +484,8 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         taps_load(pyr, t1, h, d1);
     }
     if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
-    if (two) taps_acc(t1, d1, feat);
+    else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
+    if (two) taps_acc<false>(t1, d1, feat);
     view_dir_code(ctr, tc + T_O, sc + S_C, dir);
 }
 
@@ -550,12 +557,21 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 
     for (int v = 0; v < V; ++v) {
         float* st = stage + (size_t)v * STAGE_V;
+        // gather_view defines all 22 outputs; lanes without a sample in this slot stage unspecified values (never zeroed:
+        // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) feat[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float dir[4] = {0.f, 0.f, 0.f, 0.f};
-        float rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        float dir[4], rgb[2][3];
         if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, feat, dir, rgb, skip);
+        else {
+            const float u = __builtin_nondeterministic_value(0.f);
+            feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dir[e] = u;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb[e][c] = u;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -781,7 +797,9 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     if (h == 0) {
         float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
         ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
-        ck[COMP_ALPHA + j] = act ? 1.f - __expf(-softplus_t20(sig)) : 0.f;  // utils.py:34
+        // alpha = 1 - exp(-softplus(sig)) (nerf.py:102 Softplus, utils.py:34) = 1 - 1/(1 + e^sig) = sigmoid(sig): one exp and one
+        // reciprocal instead of log1p(exp()) followed by another exp (beyond Softplus's threshold 20 the two differ by e^-40)
+        ck[COMP_ALPHA + j] = act ? frcp(1.f + __expf(-sig)) : 0.f;
     }
 }
 
