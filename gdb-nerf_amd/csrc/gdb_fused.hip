@@ -249,10 +249,18 @@ __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx
     return ((const half8*)(mf + (size_t)idx * 256))[lane];
 }
 #define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
+// ReLU as exactly one instruction: written as fmaxf(x, 0) hipcc first canonicalises an MFMA output with v_max x, x, x
+// (IEEE-mode maxnum wants quieted inputs) — two instructions per ReLU in every per-view pass.  A signed integer max on the
+// bit pattern is the same function (negative floats, -0 included, have the sign bit set) and needs no canonical input.
+// (Not inline asm: the compiler's MFMA -> VALU hazard handling does not look inside it, and a v_max_f32 written that way
+// read accumulators before the MFMA had landed.)
+__device__ __forceinline__ float relu1(float x) {
+    return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
+}
 __device__ __forceinline__ float dot16_relu(const f32x16& a, const f32x16& w) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s = fmaf(fmaxf(a[i], 0.f), w[i], s);
+    for (int i = 0; i < 16; ++i) s = fmaf(relu1(a[i]), w[i], s);
     return s;
 }
 
@@ -390,7 +398,7 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view) {
     f32x16 g = MFMA(a_view, t.T1, zero16());
 #pragma unroll
-    for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + fmaxf(g[i], 0.f);
+    for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + relu1(g[i]);
 #pragma unroll
     for (int i = 12; i < 16; ++i) g[i] = 0.f;
     return g;
@@ -662,12 +670,12 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
             f32x16 G = MFMA(a_ga0, g0, base);
             G = MFMA(a_ga1, g1, G);
             float sp = dot16_relu(G, w_agg);
-            float sv = fmaxf(sp + __shfl_xor(sp, 32) + b_agg, 0.f);  // nerf.py:79
+            float sv = relu1(sp + __shfl_xor(sp, 32) + b_agg);  // nerf.py:79
             float mn = fmaxf(mx, sv);
             float sc_old = __expf(mx - mn), e = __expf(sv - mn);
             den = den * sc_old + e;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * fmaxf(G[i], 0.f);
+            for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * relu1(G[i]);
             mx = mn;
         }
         float r = frcp(den);
@@ -709,7 +717,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         fh = MFMA(fh2, X10, fh);
         fh = MFMA(fh3, X11, fh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fhv[i] = fmaxf(fh[i], 0.f);
+        for (int i = 0; i < 4; ++i) fhv[i] = relu1(fh[i]);
         sig = fh[4];
     }
     PHASE_FENCE();
@@ -767,7 +775,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
                 hv = MFMA(c11, T1, hv);
                 up += dot16_relu(hv, w21);
             }
-            float uv = fmaxf(up + __shfl_xor(up, 32) + b_w2, 0.f);  // nerf.py:109
+            float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
             float mn = fmaxf(mx, uv);
             float sc_old = __expf(mx - mn), e = __expf(uv - mn);
             den = den * sc_old + e;
