@@ -288,10 +288,11 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsign
     tex_coord(u, W, x0, x1, fx);
     tex_coord(v, H, y0, y1, fy);
     Taps t;
-    unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): rows and widths are far below 2^24
+    unsigned r0 = __umul24(y0, W), r1 = __umul24(y1, W);
     t.o00 = lvlB + 16u * (r0 + x0); t.o10 = lvlB + 16u * (r0 + x1);
     t.o01 = lvlB + 16u * (r1 + x0); t.o11 = lvlB + 16u * (r1 + x1);
-    t.planeB = 16u * (unsigned)(W * H);
+    t.planeB = 16u * __umul24(W, H);
     float ex = (1.f - fx) * lw, wx = fx * lw;
     t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
     return t;
@@ -305,7 +306,7 @@ __device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
 // chunk 4 (channels 16+2h, 17+2h; channel 19 is padding) — the same unconditional loads in both halves, no branch.
 struct TapData { float4 t[2][4]; float2 u[4]; };
 __device__ __forceinline__ void taps_load(const void* __restrict__ pyr, const Taps& t, int h, TapData& d) {
-    const unsigned c0 = (unsigned)h * t.planeB, c1 = c0 + 2u * t.planeB, c4 = 4u * t.planeB + 8u * (unsigned)h;
+    const unsigned c0 = h ? t.planeB : 0u, c1 = c0 + 2u * t.planeB, c4 = 4u * t.planeB + 8u * (unsigned)h;
     d.t[0][0] = ldu<float4>(pyr, t.o00 + c0); d.t[0][1] = ldu<float4>(pyr, t.o10 + c0);
     d.t[0][2] = ldu<float4>(pyr, t.o01 + c0); d.t[0][3] = ldu<float4>(pyr, t.o11 + c0);
     d.t[1][0] = ldu<float4>(pyr, t.o00 + c1); d.t[1][1] = ldu<float4>(pyr, t.o10 + c1);
@@ -347,7 +348,7 @@ __device__ __forceinline__ RgbTaps rgb_taps(int Ho, int Wo, float px, float py) 
     int y1 = min(y0 + 1, Ho - 1);  // a clamped row carries weight 0 (wy = 0 at the edge)
     RgbTaps t;
     t.w00 = (1.f - wx) * (1.f - wy); t.w10 = wx * (1.f - wy); t.w01 = (1.f - wx) * wy; t.w11 = wx * wy;
-    t.o0 = 4u * (unsigned)(y0 * Wo + x0); t.o1 = 4u * (unsigned)(y1 * Wo + x0);  // byte offsets inside a colour plane
+    t.o0 = 4u * (__umul24(y0, Wo) + x0); t.o1 = 4u * (__umul24(y1, Wo) + x0);  // byte offsets inside a colour plane
     return t;
 }
 __device__ __forceinline__ void rgb_load(const float* __restrict__ img, unsigned plane, const RgbTaps& t, RgbData& d) {
@@ -521,7 +522,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
         int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
         const unsigned plane = (unsigned)(f.H * f.W), cs = plane * (unsigned)f.D;
         const float* vol = f.feat_volume + (size_t)bi * GDB_CV * cs;
-        const unsigned cb = 4u * (unsigned)h * cs;
+        const unsigned cb = h ? 4u * cs : 0u;
         if (f.W >= 2) {  // x pair in one 8-byte load (shifted left at the right edge, weight on its second element)
             int xp = min(x0, f.W - 2);
             float wxp = gx - (float)xp;
@@ -532,7 +533,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                     int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);  // a clamped tap carries weight 0
                     float wyz = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
                     float wa = (1.f - wxp) * wyz, wb = wxp * wyz;
-                    unsigned off = 4u * (cb + (unsigned)((zz * f.H + yy) * f.W + xp));
+                    unsigned off = 4u * (cb + __umul24(__umul24(zz, f.H) + yy, f.W) + xp);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         F2u pr = ldu_pin<F2u>(vol + c * cs, off);
@@ -546,7 +547,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
                 for (int dy = 0; dy < 2; ++dy) {
                     int yy = min(y0 + dy, f.H - 1), zz = min(z0 + dz, f.D - 1);
                     float wgt = (dy ? wy : 1.f - wy) * (dz ? wz : 1.f - wz);
-                    unsigned off = 4u * (cb + (unsigned)((zz * f.H + yy) * f.W));
+                    unsigned off = 4u * (cb + __umul24(__umul24(zz, f.H) + yy, f.W));
 #pragma unroll
                     for (int c = 0; c < 4; ++c) vox[c] = fmaf(ldu_pin<float>(vol + c * cs, off), wgt, vox[c]);
                 }
@@ -975,6 +976,9 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     const size_t lim = (size_t)1 << 32;
     if (L.pyrStride * 4 >= lim || (size_t)3 * fr->Ho * fr->Wo * 4 >= lim || (size_t)GDB_CV * fr->D * fr->H * fr->W * 4 >= lim)
         return gdb_fail(GDB_E_SHAPE, "frame too large for the fused kernel: a per-view pyramid, a source image or a cost volume exceeds 4 GiB");
+    // ... and forms row offsets with 24-bit multiplies
+    if (fr->Ho >= (1 << 24) || fr->Wo >= (1 << 24) || (size_t)fr->D * fr->H >= ((size_t)1 << 24))
+        return gdb_fail(GDB_E_SHAPE, "frame too large for the fused kernel: an extent (or D*H) reaches 2^24");
     FusedArgs a;
     a.f = dev_frame(*cfg, *fr, L, ws);
     a.pw = pw;
