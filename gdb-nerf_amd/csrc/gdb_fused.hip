@@ -900,10 +900,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
             rk[COMP_WN + tt] = w;
             sum += w;
         }
-        float den = fmaxf(sum, 1e-6f);
+        const float rden = 1.f / fmaxf(sum, 1e-6f);  // one division per bundle; w_k * (1/den) is within an ulp of w_k / den
         for (int k = 0; k < S; ++k) {
             float* rk = rec_team + (size_t)k * rec_stride;
-            rk[COMP_WN + tt] = rk[COMP_WN + tt] / den;
+            rk[COMP_WN + tt] = rk[COMP_WN + tt] * rden;
         }
     }
     __syncthreads();
