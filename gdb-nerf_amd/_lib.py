@@ -52,6 +52,7 @@ _SIGNATURES = {
     "gdb_build_feature_volume": (C.c_int, [_P] * 6 + [C.c_int32] * 9 + [_P, _P, _P]),
     "gdb_depth_regression": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "gdb_fused_set_schedule": (C.c_int, [C.c_int32]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -199,6 +199,12 @@ struct FusedArgs {
 };
 static unsigned* g_dbg = nullptr;
 extern "C" void gdb_debug_set_buffer(void* p) { g_dbg = (unsigned*)p; }
+static int g_schedule = 0;  // GDB_SCHED_AUTO
+extern "C" int gdb_fused_set_schedule(int32_t mode) {
+    if (mode < 0 || mode > 2) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..2", mode);
+    g_schedule = mode;
+    return GDB_OK;
+}
 
 __device__ __forceinline__ float to_h_range(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 
@@ -432,6 +438,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: 36 scalar loads, the block lives in SGPRs
     {
         const kfloat* scg = kptr(src_cam(f, bi, v));
+        asm volatile("" : "+s"(scg));  // not loop-invariant for the compiler: inside a slot loop LICM would hoist all V blocks
 #pragma unroll
         for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
     }
@@ -500,17 +507,10 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 
 // Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns
 // false (and writes an empty composite record) when no lane has a sample in this slot.
-__device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, const float* rng, int k,
-                                            int bi, int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
+// Sample slot k of the bundle q (already loaded) for this lane: the views' contributions go to the wave's staging area.
+__device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, const float* __restrict__ tc, const Bundle<4>& q, int k, int bi,
+                                              int j, int h, int skip, bool act, float& z, half8& H1) {
     const int V = f.V;
-    Bundle<4> q;
-    load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
-    act = inrow && k < q.count;
-    if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
-        for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
-        if (h == 0) ck[COMP_ALPHA + j] = 0.f;
-        return false;
-    }
     float dn, ball, xyz[4][3], ctr[3];
     bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
@@ -597,6 +597,21 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
             for (int e = 0; e < 4; ++e) st[(ROW_DIR + e) * 32 + j] = dir[e];
         }
     }
+}
+
+// Workgroup-composite kernel: loads the bundle, decides whether the slot holds a sample; returns false (and writes an
+// empty composite record) when no lane has one.
+__device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, const float* rng, int k,
+                                            int bi, int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
+    Bundle<4> q;
+    load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
+    act = inrow && k < q.count;
+    if (!__any(act)) {  // wave-uniform: nothing to sample in this slot
+        for (int c = h; c < COMP_CH; c += 2) ck[c * COMP_LD + j] = 0.f;
+        if (h == 0) ck[COMP_ALPHA + j] = 0.f;
+        return false;
+    }
+    slot_gather_q(f, stage, tc, q, k, bi, j, h, skip, act, z, H1);
     return true;
 }
 
@@ -609,9 +624,11 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // phase's fragments (they fly under this phase's MFMAs and VALU work), then computes with fragments loaded one phase
 // earlier.  The fences keep the compiler from moving the loads any further (hoisting all ~45 of them spills), so
 // without this each phase's first MFMA waits a full L2 round trip.
+// Outputs per lane (j, h): bacc[i] = blended channel 16h+i of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
+// channel 4h+i, sig = sigma pre-activation (valid in half 0).
 template <int VT, bool GW>
-__device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
-                                         const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
+__device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const half8 H1, int lane, int j,
+                                              int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
     const int V = VT > 0 ? VT : f.V;
     constexpr int NC = VT > 0 ? VT : 1, UNR = VT > 0 ? VT : 1;
     half8 cT0[NC], cT1[NC], cG0[NC], cG1[NC];  // per-view fragment cache (VT > 0 only)
@@ -706,7 +723,6 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
         X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
     }
     PHASE_FENCE();
-    float fhv[4], sig;
     half8 wa0, wa1, wa2, wa3, wb0, wb1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
         wa0 = load_frag<GW>(mf, F_W0A + 0, lane_o); wa1 = load_frag<GW>(mf, F_W0A + 1, lane_o);  // next phase
@@ -754,7 +770,6 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     PHASE_FENCE();
     STAMP(5);
     // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
-    float bacc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
@@ -795,6 +810,18 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     STAMP(6);
+}
+
+// alpha = 1 - exp(-softplus(sig)) (nerf.py:102 Softplus, utils.py:34) = 1 - 1/(1 + e^sig) = sigmoid(sig): one exp and one
+// reciprocal instead of log1p(exp()) followed by another exp (beyond Softplus's threshold 20 the two differ by e^-40)
+__device__ __forceinline__ float alpha_of(float sig) { return frcp(1.f + __expf(-sig)); }
+
+// Workgroup-composite kernel: MLP of one slot, then the slot's composite record.
+template <int VT, bool GW>
+__device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
+                                         const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
+    float bacc[16], fhv[4], sig;
+    slot_mlp_core<VT, GW>(f, mf, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -806,9 +833,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     if (h == 0) {
         float zz = f.inv_depth ? 1.f / z : z;  // network.py:83-84
         ck[NOUT * COMP_LD + j] = act ? zz : 0.f;
-        // alpha = 1 - exp(-softplus(sig)) (nerf.py:102 Softplus, utils.py:34) = 1 - 1/(1 + e^sig) = sigmoid(sig): one exp and one
-        // reciprocal instead of log1p(exp()) followed by another exp (beyond Softplus's threshold 20 the two differ by e^-40)
-        ck[COMP_ALPHA + j] = act ? frcp(1.f + __expf(-sig)) : 0.f;
+        ck[COMP_ALPHA + j] = act ? alpha_of(sig) : 0.f;
     }
 }
 
@@ -936,6 +961,130 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     STAMP(9);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One wave = one 32-bundle row segment and ALL its sample slots, one after the other; the composite runs in registers.
+// Against the workgroup-composite kernel above this drops the per-slot LDS record, the barrier wait for the slowest
+// slot and the composite pass, and a frame's waves fit on the chip in fewer rounds (c2: 2560 waves, one round).
+// Lane (j, h) owns blended channels 16h..16h+15 and feat_head channels 4h..4h+3 of bundle j; transmittance, weight
+// sum and depth are kept by both halves.  utils.py:35-41 (weights), :109-119 (sums), network.py:83-89 (depth).
+__global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
+    float* stage = (float*)smem4;  // V x STAGE_V floats; reused for the output transpose at the end
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    // Everything wave-uniform (kernel arguments, camera block, pointers) is re-derived inside each slot iteration from
+    // an opaque pointer to the kernel arguments: as loop invariants they would be live across the whole loop body and
+    // the compiler spills ~130 SGPRs and ~50 VGPRs around every slot.  Only the composite state lives across slots.
+    // (the kernel-argument segment itself, constant address space: &a_ would be a private copy of the struct)
+    typedef const FusedArgs __attribute__((address_space(4))) KArgs;
+    KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    int cnt, seg, row, bi;
+    float rng[4];
+    {
+        const FusedArgs& a = *(const FusedArgs*)ap;
+        const DevFrame& f = a.f;
+        const int chunk = (a.ntiles + 7) >> 3;  // XCD-aware tile order, as above
+        const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        if (tile >= a.ntiles) return;
+        seg = tile % a.nseg;
+        const int rr = tile / a.nseg;
+        row = a.row_begin + rr % a.nrows; bi = rr / a.nrows;
+        const int x = seg * 32 + j;
+        load_ranges(f, bi, row, min(x, f.W - 1), rng);
+        float tc[TAR_STRIDE];
+        const kfloat* tcg = kptr(tar_cam(f, bi));
+#pragma unroll
+        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
+        Bundle<4> q0;
+        load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q0, rng);
+        cnt = x < f.W ? q0.count : 0;
+    }
+    float oacc[16], of[4], dz = 0.f, T = 1.f, wsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) of[i] = 0.f;
+    const int S = ap->f.S_max;
+    for (int k = 0; k < S; ++k) {
+        const bool act = k < cnt;
+        if (!__any(act)) break;  // a bundle's samples are slots 0..count-1: nothing left in this segment
+        KArgs* apk = ap;
+        asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
+        const FusedArgs& a = *(const FusedArgs*)apk;
+        const DevFrame& f = a.f;
+        unsigned* dbg = a.dbg; (void)dbg;
+        seg = __builtin_amdgcn_readfirstlane(seg); row = __builtin_amdgcn_readfirstlane(row); bi = __builtin_amdgcn_readfirstlane(bi);
+        const int x = seg * 32 + j;
+        float tc[TAR_STRIDE];
+        {
+            const kfloat* tcg = kptr(tar_cam(f, bi));
+            asm volatile("" : "+s"(tcg));
+#pragma unroll
+            for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
+        }
+        const float* mfg = a.pw + PW_FP32_FLOATS;
+        const float b_agg = kptr(mfg)[TS_BAGG], b_w2 = kptr(mfg)[TS_BW2];
+        float z; half8 H1;
+        {
+            Bundle<4> q;  // recomputed per slot from the pre-loaded ranges: cheaper than ~24 registers live across the loop
+            load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
+            slot_gather_q(f, stage, tc, q, k, bi, j, h, a.skip, act, z, H1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        PHASE_FENCE();
+        float bacc[16], fhv[4], sig;
+        slot_mlp_core<0, true>(f, mfg, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        const float sig0 = __shfl(sig, j);  // sigma sits in half 0
+        if (act) {  // lanes without a sample hold unspecified MLP outputs: keep them out of the sums
+            const float al = alpha_of(sig0);
+            const float w = al * T;
+            T = T * (1.f - al);
+            wsum += w;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[i] = fmaf(w, bacc[i], oacc[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) of[i] = fmaf(w, fhv[i], of[i]);
+            dz = fmaf(w, f.inv_depth ? 1.f / z : z, dz);
+        }
+        PHASE_FENCE();
+    }
+    // normalise, transpose through LDS, store the segment's (32 x 39) block as one contiguous run
+    const FusedArgs& a = *(const FusedArgs*)ap;
+    const DevFrame& f = a.f;
+    const float rden = 1.f / fmaxf(wsum, 1e-6f);
+    __builtin_amdgcn_wave_barrier();
+    float* o = stage;  // [NOUT + 2][COMP_LD]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int c = 16 * h + i;
+        if (c < NBLEND) o[c * COMP_LD + j] = oacc[i] * rden;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + j] = of[i] * rden;
+    if (h == 0) { o[NOUT * COMP_LD + j] = dz * rden; o[(NOUT + 1) * COMP_LD + j] = wsum * rden; }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    const int nvalid = min(32, f.W - seg * 32);
+    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
+    for (int qi = lane; qi < nvalid * NOUT; qi += 64) {
+        int jj = qi / NOUT, c = qi - jj * NOUT;
+        a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
+    }
+    if (j < nvalid) {
+        if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
+        else { float d = o[NOUT * COMP_LD + j]; a.depth[b0 + j] = f.inv_depth ? 1.f / d : d; }
+    }
+}
+
+static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_solo, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_render_solo, dim3(grid), dim3(64), lds, st, a);
+    return hipGetLastError();
+}
+
 template <bool LDSW, bool LOOP, int WAVES, int VT>
 static hipError_t launch_fused_v(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
     static bool attr = false;
@@ -1008,7 +1157,19 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
         while (teams > 0 && wbytes + (size_t)teams * S * per_wave > lds_max) --teams;
         if ((size_t)teams > (size_t)a.nsegs) teams = a.nsegs;
     }
-    if (teams > 0) {
+    // Two schedules (gdb_fused_set_schedule; measured on MI355X, profiles/r01/schedules.txt):
+    //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
+    //                  nearly every slot holds a sample: S_max = 3 (c2 62 vs 72 us, c3 105 vs 126 us).
+    //  * segment wave - one wave walks all slots of its segment, composite in registers.  Best when slots are sparsely
+    //                  filled or the S-wave workgroup is LDS-limited: c4 (S_max 6 adaptive) 171 vs 296 us, c5 1346 vs 1490 us.
+    static const char* env_sched = getenv("GDB_FUSED_SOLO");  // experiment override: "0" slot waves, "1" segment wave
+    const int sched = env_sched ? (env_sched[0] == '0' ? 1 : 2) : g_schedule;
+    const bool want_solo = sched == 2 || (sched == 0 && S > 3);
+    const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
+    if (want_solo && !allow_ldsw && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
+        a.teams = 1; a.alias = 0; a.ntiles = a.nsegs;
+        e = launch_solo(a, (unsigned)((a.ntiles + 7) / 8 * 8), solo_lds, st);
+    } else if (teams > 0) {
         const int nw = teams * S;
         a.teams = teams; a.alias = 1; a.ntiles = (a.nsegs + teams - 1) / teams;
         const size_t lds = wbytes + (size_t)nw * per_wave;

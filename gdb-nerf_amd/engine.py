@@ -145,6 +145,11 @@ class HotPathEngine:
         self._frame, self._keep = f, dict(frame)
         _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
 
+    def set_schedule(self, mode: int) -> None:
+        """Work decomposition of the fused kernel (process-wide): 0 auto, 1 one wave per sample slot, 2 one wave per
+        32-bundle segment.  See include/gdb_nerf_hip.h."""
+        _lib.check(self.lib.gdb_fused_set_schedule(int(mode)))
+
     def feature_pyramid(self):
         """The mip pyramid `prepare` built, as nvdiffrast would hold it: a list over levels of
         (B, V, H_l, W_l, C_f+3) tensors (copies; the workspace keeps the chunk-planar layout)."""

@@ -184,6 +184,14 @@ int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const 
                              int32_t precision, float* d_bundle_feat, float* d_depth, float* d_opacity,
                              void* stream);
 
+/* Work decomposition of gdb_render_bundles_fused (process-wide tuning knob; results agree to rounding):
+ * 0 GDB_SCHED_AUTO (default: by shape), 1 GDB_SCHED_SLOT_WAVES (one wave per sample slot, composite through
+ * LDS), 2 GDB_SCHED_SEGMENT_WAVE (one wave walks all slots of its 32 bundles, composite in registers). */
+#define GDB_SCHED_AUTO 0
+#define GDB_SCHED_SLOT_WAVES 1
+#define GDB_SCHED_SEGMENT_WAVE 2
+int gdb_fused_set_schedule(int32_t mode);
+
 /* ---- "next" rows: the step just before the hot path ------------------------ */
 /* build_feature_volume, networks/gdb_nerf/depth_net.py:424-476: plane-sweep warp of the source feature maps
  * d_src_feat (B,V,C,Hs,Ws) onto the target frustum planes d_depth_values (B,D,Ht,Wt) (depth or, with

@@ -29,6 +29,15 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.fixture(params=[1, 2], ids=["slot-waves", "segment-wave"])
+def schedule(request):
+    """Both work decompositions of the fused kernel (include/gdb_nerf_hip.h GDB_SCHED_*); back to auto afterwards."""
+    eng = HotPathEngine()
+    eng.set_schedule(request.param)
+    yield request.param
+    eng.set_schedule(0)
+
+
 def engine_for(frame, weights=None, **cfg):
     eng = HotPathEngine(**cfg)
     if weights is not None:
@@ -210,7 +219,7 @@ def _psnr_delta(bf_a, bf_b, H, W):
 
 
 @pytest.mark.parametrize("tag", ["dtu", "mips"])
-def test_fused_vs_golden(tag):
+def test_fused_vs_golden(tag, schedule):
     fx = load_golden("F6_hotpath_" + tag)
     eng = engine_for(frame_of(fx), nerf_weights_of(fx), max_num_samples=int(fx["S_max"]),
                      is_adaptive=bool(fx["adaptive"]), inv_depth=bool(fx["inv_depth"]))
@@ -229,7 +238,7 @@ def test_fused_vs_golden(tag):
     (48, 80, 2, 1, 3, True, False, "llff"),
     (32, 64, 5, 1, 8, True, False, "dtu"),     # 5 views, 8 slots
 ])
-def test_fused_vs_oracle(Ho, Wo, V, B, S, adaptive, inv, scene):
+def test_fused_vs_oracle(Ho, Wo, V, B, S, adaptive, inv, scene, schedule):
     frame = synthetic.make_frame(Ho, Wo, V=V, B=B, scene=scene, seed=21, src_focal_scale=(1.0, 1.9, 3.3))
     w = synthetic.make_nerf_weights(seed=5)
     with np.errstate(all="ignore"):
@@ -251,7 +260,7 @@ def test_fused_vs_oracle(Ho, Wo, V, B, S, adaptive, inv, scene):
     (64, 80, 3, 3, True, {"max_mipmap_level": 0}),       # no mip chain: bilinear on level 0 only
     (64, 80, 3, 4, True, {"global_num_depth": 8}),       # coarse prior grid -> wide adaptive intervals
 ])
-def test_fused_config_corners(Ho, Wo, V, S, adaptive, extra):
+def test_fused_config_corners(Ho, Wo, V, S, adaptive, extra, schedule):
     """Limits of the C ABI (include/gdb_nerf_hip.h GDB_MAX_*) and the config switches the reference exposes
     (nerf.viewdir_agg, nerf.max_mipmap_level, nerf.global_num_depth), fused kernel vs the oracle."""
     frame = synthetic.make_frame(Ho, Wo, V=V, scene="dtu", seed=33, src_focal_scale=(1.0, 2.3))
@@ -288,7 +297,7 @@ def _degenerate(kind, f):
 
 
 @pytest.mark.parametrize("kind", ["faces_away", "src_at_target", "duplicate_views", "zero_width_prior", "all_zero"])
-def test_fused_degenerate_geometry(kind):
+def test_fused_degenerate_geometry(kind, schedule):
     """Degenerate frames the reference handles through its clamps (z >= 1e-6, F.normalize eps, border
     padding): both device paths must follow the oracle there, and stay finite."""
     frame = _degenerate(kind, synthetic.make_frame(64, 80, V=3, scene="dtu", seed=5))
@@ -307,7 +316,7 @@ def test_fused_degenerate_geometry(kind):
     assert max_abs(npy(opac), oo) <= 1e-5
 
 
-def test_fused_matches_unfused_at_full_size():
+def test_fused_matches_unfused_at_full_size(schedule):
     """c2 (BASELINE.json configs[1]) is too big for the oracle in a test; at full size the fused kernel is
     checked against the fp32 operator chain, itself oracle-checked above, plus size-independent properties."""
     frame = synthetic.make_frame(512, 640, V=3, seed=0)
@@ -327,7 +336,7 @@ def test_fused_matches_unfused_at_full_size():
     assert _psnr_delta(npy(bf), npy(ubf), 256, 320) <= 0.05
 
 
-def test_fused_is_deterministic_at_full_size():
+def test_fused_is_deterministic_at_full_size(schedule):
     """Regression for a race seen only with several workgroups per CU at full frame size (stale lanes in a
     packed-f32 result): repeated launches must agree bit for bit, and with the fp32 operator chain."""
     frame = synthetic.make_frame(512, 640, V=3, seed=3)
@@ -339,7 +348,7 @@ def test_fused_is_deterministic_at_full_size():
     assert max_abs(npy(ref), npy(ubf)) <= FUSED_TOL
 
 
-def test_fused_row_strips_tile_the_frame():
+def test_fused_row_strips_tile_the_frame(schedule):
     """Row-strip launches (the multi-GPU shard unit) reproduce the full-frame launch bit for bit."""
     frame = synthetic.make_frame(64, 80, V=3, B=2, seed=4)
     w = synthetic.make_nerf_weights(seed=1)
@@ -364,3 +373,19 @@ def test_single_view_is_rejected_by_fused_and_nan_in_mirror():
         eng.render()
     bf, _, _ = eng.render_unfused()
     assert torch.isnan(bf).all()
+
+
+def test_fused_schedules_agree_and_reject_bad_mode():
+    """The two decompositions differ only in where the composite sums are formed (order of roundings)."""
+    frame = synthetic.make_frame(96, 144, V=3, B=1, seed=9)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=4), max_num_samples=5, is_adaptive=True)
+    try:
+        eng.set_schedule(1); a = [t.clone() for t in eng.render()]
+        eng.set_schedule(2); b = [t.clone() for t in eng.render()]
+    finally:
+        eng.set_schedule(0)
+    assert max_abs(npy(a[0]), npy(b[0])) <= 2e-6
+    assert max_abs(npy(a[1]), npy(b[1])) <= 2e-6 * float(a[1].abs().max())
+    assert max_abs(npy(a[2]), npy(b[2])) <= 2e-6
+    with pytest.raises(ValueError, match="schedule"):
+        eng.set_schedule(3)
