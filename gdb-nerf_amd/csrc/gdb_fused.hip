@@ -837,6 +837,78 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     }
 }
 
+// Composite of one segment from its S slot records in LDS (all threads of the team; two workgroup barriers inside):
+// transmittance weights per bundle, normalised (utils.py:35-41), then the weighted sums (utils.py:109-119) written as
+// the segment's contiguous (32 x 39) block, depth and opacity (network.py:88-89).  SC > 0: S == SC at compile time.
+template <int SC>
+__device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, size_t rec_stride, int S_rt, int tt, int tthreads,
+                                          bool has_seg, int seg, int row, int bi) {
+    const DevFrame& f = a.f;
+    const int S = SC > 0 ? SC : S_rt;
+    constexpr int NK = SC > 0 ? SC : 1;
+    if (tt < 32) {
+        if (SC > 0) {
+            float al[NK], w[NK], T = 1.f, sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) al[k] = rec_team[(size_t)k * rec_stride + COMP_ALPHA + tt];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { w[k] = al[k] * T; T = T * (1.f - al[k]); sum += w[k]; }
+            const float rden = 1.f / fmaxf(sum, 1e-6f);  // one division per bundle; w_k * (1/den) is within an ulp of w_k / den
+#pragma unroll
+            for (int k = 0; k < NK; ++k) rec_team[(size_t)k * rec_stride + COMP_WN + tt] = w[k] * rden;
+        } else {
+            float T = 1.f, sum = 0.f;
+            for (int k = 0; k < S; ++k) {
+                float* rk = rec_team + (size_t)k * rec_stride;
+                float al = rk[COMP_ALPHA + tt];
+                float w = al * T;
+                T = T * (1.f - al);
+                rk[COMP_WN + tt] = w;
+                sum += w;
+            }
+            const float rden = 1.f / fmaxf(sum, 1e-6f);
+            for (int k = 0; k < S; ++k) {
+                float* rk = rec_team + (size_t)k * rec_stride;
+                rk[COMP_WN + tt] = rk[COMP_WN + tt] * rden;
+            }
+        }
+    }
+    __syncthreads();
+    if (!has_seg) return;
+    const int nvalid = min(32, f.W - seg * 32);
+    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
+    for (int qi = tt; qi < nvalid * NOUT; qi += tthreads) {
+        int jj = qi / NOUT, c = qi - jj * NOUT;
+        float acc = 0.f;
+        if (SC > 0) {
+            float v[NK], w[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { const float* rk = rec_team + (size_t)k * rec_stride; v[k] = rk[c * COMP_LD + jj]; w[k] = rk[COMP_WN + jj]; }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc += v[k] * w[k];
+        } else {
+            for (int k = 0; k < S; ++k) {
+                const float* rk = rec_team + (size_t)k * rec_stride;
+                acc += rk[c * COMP_LD + jj] * rk[COMP_WN + jj];
+            }
+        }
+        a.bf[b0 * NOUT + qi] = acc;
+    }
+    if (tt < 64) {
+        int jj = tt & 31, which = tt >> 5;
+        if (jj < nvalid) {
+            float acc = 0.f;
+            for (int k = 0; k < S; ++k) {
+                const float* rk = rec_team + (size_t)k * rec_stride;
+                float w = rk[COMP_WN + jj];
+                acc += which ? w : rk[NOUT * COMP_LD + jj] * w;
+            }
+            if (which) a.opac[b0 + jj] = acc;
+            else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
+        }
+    }
+}
+
 // Workgroup = `teams` segments x S sample slots (one wave per slot); LOOP: one segment, waves loop
 // over slots.  LDSW: the MFMA section of the weights is copied to LDS once per workgroup and shared.
 template <bool LDSW, bool LOOP, int WAVES, int VT>
@@ -912,51 +984,16 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     STAMP(7);
     __syncthreads();
     STAMP(8);
-    // transmittance weights per bundle, normalised   utils.py:35-41
     const int tt = threadIdx.x - team * S * 64;  // thread index inside the team
     const int tthreads = LOOP ? (int)blockDim.x : S * 64;
-    if (tt < 32) {
-        float T = 1.f, sum = 0.f;
-        for (int k = 0; k < S; ++k) {
-            float* rk = rec_team + (size_t)k * rec_stride;
-            float al = rk[COMP_ALPHA + tt];
-            float w = al * T;
-            T = T * (1.f - al);
-            rk[COMP_WN + tt] = w;
-            sum += w;
-        }
-        const float rden = 1.f / fmaxf(sum, 1e-6f);  // one division per bundle; w_k * (1/den) is within an ulp of w_k / den
-        for (int k = 0; k < S; ++k) {
-            float* rk = rec_team + (size_t)k * rec_stride;
-            rk[COMP_WN + tt] = rk[COMP_WN + tt] * rden;
-        }
-    }
-    __syncthreads();
-    if (!has_seg) return;
-    // weighted sums; the segment's (N_b, 39) rows are one contiguous run in memory   utils.py:109-119
-    const int nvalid = min(32, f.W - seg * 32);
-    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
-    for (int qi = tt; qi < nvalid * NOUT; qi += tthreads) {
-        int jj = qi / NOUT, c = qi - jj * NOUT;
-        float acc = 0.f;
-        for (int k = 0; k < S; ++k) {
-            const float* rk = rec_team + (size_t)k * rec_stride;
-            acc += rk[c * COMP_LD + jj] * rk[COMP_WN + jj];
-        }
-        a.bf[b0 * NOUT + qi] = acc;
-    }
-    if (tt < 64) {
-        int jj = tt & 31, which = tt >> 5;
-        if (jj < nvalid) {
-            float acc = 0.f;
-            for (int k = 0; k < S; ++k) {
-                const float* rk = rec_team + (size_t)k * rec_stride;
-                float w = rk[COMP_WN + jj];
-                acc += which ? w : rk[NOUT * COMP_LD + jj] * w;
-            }
-            if (which) a.opac[b0 + jj] = acc;
-            else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
-        }
+    // The slot count is tiny: with it as a compile-time constant the S reads of a sum are all in flight before the first
+    // is used (as a runtime loop every iteration waited for its own LDS read).
+    switch (S) {
+        case 1: composite<1>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
+        case 2: composite<2>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
+        case 3: composite<3>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
+        case 4: composite<4>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
+        default: composite<0>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
     }
     STAMP(9);
 }
