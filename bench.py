@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="frames", choices=["frames", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="fused path only: render consecutive (independent) frames on this many HIP streams with their own workspaces, "
+                         "so one frame's fill/drain overlaps the next; per-launch durations then overlap too (default 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,17 +128,39 @@ def main():
     frame_np = synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=seed)
     weights_np = synthetic.make_nerf_weights(seed=0)
     frame = to_dev(frame_np, dev)
-    eng = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"], device=dev)
-    eng.load_weights(weights_np)
+    if args.streams > 1 and (args.path != "fused" or (world > 1 and args.shard == "rows")):
+        raise SystemExit("--streams > 1 is for the fused path on independent frames")
     H = Ho // 2
     r0, r1 = row_strip(H, rank, world) if args.shard == "rows" else (0, H)
-    eng.prepare(frame)
+    lanes = []  # one (engine, output buffers, stream) per stream; stream 0 is the current stream
+    for i in range(max(1, args.streams)):
+        e = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"], device=dev)
+        e.load_weights(weights_np)
+        e.prepare(frame)
+        nb = e.n_bundles
+        o = (torch.zeros((nb, e.Q), device=dev), torch.zeros((nb,), device=dev), torch.zeros((nb,), device=dev))
+        lanes.append((e, o, torch.cuda.current_stream(dev) if i == 0 else torch.cuda.Stream(dev)))
+    torch.cuda.synchronize()
+    eng, out, _ = lanes[0]
     nb = eng.n_bundles
-    out = (torch.zeros((nb, eng.Q), device=dev), torch.zeros((nb,), device=dev), torch.zeros((nb,), device=dev))
 
     ev_pairs = []
+    counter = [0]
 
     def step(timed):
+        if args.streams > 1:  # frame i on stream i % n: prepare + render back to back on that stream
+            e, o, st = lanes[counter[0] % len(lanes)]
+            counter[0] += 1
+            with torch.cuda.stream(st):
+                e.prepare(frame)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                e.render(r0, r1, 0, o)
+                if timed:
+                    e1.record()
+                    ev_pairs.append((e0, e1))
+            return
         eng.prepare(frame)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -215,7 +240,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 fetch/composite, f16 MFMA MLP (f32 accumulate)" if args.path == "fused" else "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
-                   "path": args.path, "shard": args.shard if world > 1 else "none", "prewarm_ms": args.prewarm_ms},
+                   "path": args.path, "shard": args.shard if world > 1 else "none", "prewarm_ms": args.prewarm_ms, "streams": args.streams},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "alg_bytes": ab},
     }
