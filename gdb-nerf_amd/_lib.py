@@ -53,6 +53,7 @@ _SIGNATURES = {
     "gdb_depth_regression": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gdb_fused_set_schedule": (C.c_int, [C.c_int32]),
+    "gdb_merge": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

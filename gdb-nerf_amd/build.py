@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdbnerf_hip.so")
-SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip")
+SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip", "gdb_merge.hip")
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 mul/add into v_pk_*_f32 with op_sel
 # modifiers; in the fused kernel that produced stale values in lanes 48..63 of one packed result
 # whenever two or more workgroups shared a CU (run-to-run different bundles, found with
@@ -17,7 +17,7 @@ SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
 # the fused fast path lets the compiler contract.
-CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off"}
+CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off"}
 
 
 def _stale() -> bool:

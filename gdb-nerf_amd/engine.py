@@ -145,6 +145,29 @@ class HotPathEngine:
         self._frame, self._keep = f, dict(frame)
         _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
 
+    # ---- next row N1: merge around the decoder ------------------------------------------------
+    def merge(self, bundle_feat, rgb_c=None, bundle_depth=None, bundle_opacity=None, reweighting: bool = False):
+        """network.py:170-182 on the frame last prepared: img = rgb_c + pixel_shuffle(bundle_feat[:, :3 b^2], b) (re-weighted
+        if asked), bundle depth / opacity maps upsampled x b.  Returns (img (B,3,Ho,Wo), depth (B,Ho,Wo) | None, opacity | None)."""
+        f = self._need_frame()
+        nb, b = self.n_bundles, self.cfg.bundle_size
+        Ho, Wo = f.H * b, f.W * b
+        _chk(bundle_feat, "bundle_feat", (nb, self.Q))
+        if rgb_c is not None:
+            _chk(rgb_c, "rgb_c", (f.B, 3, Ho, Wo))
+        img = torch.empty((f.B, 3, Ho, Wo), device=self.device)
+        outs = []
+        for name, m in (("bundle_depth", bundle_depth), ("bundle_opacity", bundle_opacity)):
+            if m is not None:
+                _chk(m, name, (nb,))
+                outs.append(torch.empty((f.B, Ho, Wo), device=self.device))
+            else:
+                outs.append(None)
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self.lib.gdb_merge(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), p(rgb_c), p(bundle_depth), p(bundle_opacity),
+                                      int(bool(reweighting)), img.data_ptr(), p(outs[0]), p(outs[1]), self._stream()))
+        return img, outs[0], outs[1]
+
     def set_schedule(self, mode: int) -> None:
         """Work decomposition of the fused kernel (process-wide): 0 auto, 1 one wave per sample slot, 2 one wave per
         32-bundle segment.  See include/gdb_nerf_hip.h."""

@@ -107,6 +107,7 @@ class Network(nn.Module):
         rgb_lo = F.interpolate(src_images.flatten(0, 1), size=(H, W), mode="bilinear", align_corners=False).unflatten(0, (B, V))
         img_feat_rgb = torch.cat((img_feat, rgb_lo), dim=2)
 
+        eng = None
         if self.hot_path == "fused":
             c = lambda t: t.contiguous().float()
             eng = self._get_engine(src_images.device)
@@ -124,6 +125,9 @@ class Network(nn.Module):
         nerf_feat = bundle_feat.view(B, H, W, -1).permute(0, 3, 1, 2)
         n_rgb = 3 * b * b
         rgb_c = self.upsampler(nerf_feat[:, n_rgb:])
+        if eng is not None:  # N1: pixel-shuffle + add (+ re-weighting) + the two x b upsamplings in one HIP kernel
+            img, nerf_depth, opacity = eng.merge(bundle_feat, rgb_c.contiguous().float(), bundle_depth, bundle_opacity, self.reweighting)
+            return {"rgb": img, "nerf_depth": nerf_depth, "mvs_depth": mvs_depth, "opacity": opacity}, mvs_depths, blend_rgbs
         rgb_f = F.pixel_shuffle(nerf_feat[:, :n_rgb], b)
         up = lambda t: F.interpolate(t.view(B, 1, H, W), scale_factor=b, mode="bilinear", align_corners=False).squeeze(1)
         img = rgb_c + rgb_f

@@ -208,6 +208,15 @@ int gdb_build_feature_volume(const float* d_src_feat, const float* d_src_exts, c
 int gdb_depth_regression(const float* d_depth_values, const float* d_depth_prob, int32_t B, int32_t D, int32_t H, int32_t W,
                          float ci_scale, int32_t inv_depth, float* d_depth, float* d_ci, void* stream);
 
+/* ---- merge around the decoder (next row N1) --------------------------------------------- */
+/* network.py:170-182.  rgb_f = pixel_shuffle(bundle_feat[:, :3 b^2], b); img = rgb_c + rgb_f (rgb_c = the decoder's
+ * (B,3,Ho,Wo) output, NULL = zeros); reweighting != 0: img = 0.5 (img + rgb_f).  d_out_depth / d_out_opacity
+ * (B,Ho,Wo), either may be NULL: F.interpolate(scale_factor=b, mode='bilinear', align_corners=False) of the
+ * (B,H,W) bundle maps.  shape needs B, H, W (Ho = H b, Wo = W b). */
+int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, const float* d_rgb_c,
+              const float* d_bundle_depth, const float* d_bundle_opacity, int32_t reweighting, float* d_img,
+              float* d_out_depth, float* d_out_opacity, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -603,3 +603,40 @@ def depth_regression(depth_values: np.ndarray, depth_prob: np.ndarray, ci_scale:
         ci = (F32(1) / np.concatenate((np.minimum(mean + half, first), np.maximum(mean - half, last)), axis=1)).astype(F32)
         return (F32(1) / mean).astype(F32), ci
     return mean, np.concatenate((np.maximum(mean - half, first), np.minimum(mean + half, last)), axis=1).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# N1  merge around the decoder    (network.py:170-182)
+# ----------------------------------------------------------------------------------------
+def upsample_bilinear(x: np.ndarray, scale: int) -> np.ndarray:
+    """F.interpolate(x[:, None], scale_factor=scale, mode='bilinear', align_corners=False) of (B,H,W) maps:
+    src = (dst + 0.5) / scale - 0.5, clamped at 0; taps i0 = floor(src), i1 = min(i0 + 1, n - 1)."""
+    x = _f(x)
+    B, H, W = x.shape
+
+    def taps(n_in, n_out):
+        src = np.maximum((np.arange(n_out, dtype=F32) + F32(0.5)) * F32(1.0 / scale) - F32(0.5), F32(0)).astype(F32)
+        i0 = np.floor(src).astype(np.int64)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(F32)).astype(F32)
+        return i0, i1, (F32(1) - l1).astype(F32), l1
+
+    y0, y1, ly0, ly1 = taps(H, H * scale)
+    x0, x1, lx0, lx1 = taps(W, W * scale)
+    top = (lx0[None, None, :] * x[:, y0][:, :, x0] + lx1[None, None, :] * x[:, y0][:, :, x1]).astype(F32)
+    bot = (lx0[None, None, :] * x[:, y1][:, :, x0] + lx1[None, None, :] * x[:, y1][:, :, x1]).astype(F32)
+    return (ly0[None, :, None] * top + ly1[None, :, None] * bot).astype(F32)
+
+
+def merge(bundle_feat: np.ndarray, rgb_c: np.ndarray, bundle_depth: np.ndarray, bundle_opacity: np.ndarray, B: int, H: int, W: int,
+          bundle_size: int = 2, reweighting: bool = False):
+    """network.py:170-182: rgb_f = pixel_shuffle(bundle_feat[:, :3 b^2], b); img = rgb_c + rgb_f, and with
+    reweighting img = 0.5 (img + rgb_f); bundle depth / opacity maps upsampled x b (bilinear, align_corners False).
+    bundle_feat (B*H*W, Q), rgb_c (B,3,H b,W b) -> img (B,3,H b,W b), depth (B,H b,W b), opacity (B,H b,W b)."""
+    b = bundle_size
+    bf = _f(bundle_feat).reshape(B, H, W, -1)[..., :3 * b * b].reshape(B, H, W, 3, b, b)  # channel c*b^2 + dy*b + dx
+    rgb_f = np.transpose(bf, (0, 3, 1, 4, 2, 5)).reshape(B, 3, H * b, W * b)
+    img = (_f(rgb_c) + rgb_f).astype(F32)
+    if reweighting:
+        img = (F32(0.5) * (img + rgb_f)).astype(F32)
+    return img, upsample_bilinear(_f(bundle_depth).reshape(B, H, W), b), upsample_bilinear(_f(bundle_opacity).reshape(B, H, W), b)

@@ -427,3 +427,34 @@ def test_fused_random_shapes_vs_fp32_chain(case, schedule):
     eng.render(0, cut, 0, out); eng.render(cut, H, 0, out)
     for a, b in zip((bf, depth, opac), out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("b,rew,B,Ho,Wo", [(2, False, 1, 64, 80), (2, True, 2, 48, 72), (4, False, 1, 64, 96), (1, True, 1, 10, 14), (2, False, 1, 512, 640)])
+def test_merge_vs_oracle_and_torch(b, rew, B, Ho, Wo):
+    """N1 (network.py:170-182): gdb_merge against the oracle (exact for the image, ulp-level for the upsampled maps) and
+    against the torch calls the reference makes."""
+    import torch.nn.functional as F
+    frame = synthetic.make_frame(Ho, Wo, V=2, B=B, bundle_size=b, seed=6)
+    eng = engine_for(frame, bundle_size=b)
+    H, W, Q = Ho // b, Wo // b, eng.Q
+    rng = np.random.default_rng(12)
+    bf = rng.standard_normal((B * H * W, Q)).astype(np.float32)
+    rgb_c = rng.standard_normal((B, 3, Ho, Wo)).astype(np.float32)
+    dep = rng.uniform(400, 900, (B * H * W,)).astype(np.float32)
+    opa = rng.uniform(0, 1, (B * H * W,)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    img, d, o = eng.merge(t(bf), t(rgb_c), t(dep), t(opa), rew)
+    oimg, od, oo = oracle.merge(bf, rgb_c, dep, opa, B, H, W, b, rew)
+    assert np.array_equal(npy(img), oimg)
+    assert max_abs(npy(d), od) <= 3e-7 * 900 and max_abs(npy(o), oo) <= 3e-7
+    nerf_feat = torch.from_numpy(bf).view(B, H, W, -1).permute(0, 3, 1, 2)
+    rgb_f = F.pixel_shuffle(nerf_feat[:, :3 * b * b], b)
+    ref = torch.from_numpy(rgb_c) + rgb_f
+    if rew:
+        ref = 0.5 * (ref + rgb_f)
+    assert np.array_equal(npy(img), ref.numpy())
+    # decoder output absent, maps not requested
+    img0, d0, o0 = eng.merge(t(bf))
+    assert d0 is None and o0 is None and np.array_equal(npy(img0), rgb_f.numpy())
+    with pytest.raises(ValueError, match="bundle_feat"):
+        eng.merge(t(bf)[:-1])

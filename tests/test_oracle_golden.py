@@ -137,3 +137,26 @@ def test_psnr():
     m = np.ones((8, 8), bool)
     expect = 10 * np.log10(1.0 / np.mean((gt - np.clip(pred, 0, 1)) ** 2))
     assert abs(oracle.psnr(gt, pred, m) - expect) < 1e-9
+
+
+@pytest.mark.parametrize("b,rew", [(2, False), (2, True), (4, False), (1, True)])
+def test_merge_matches_torch_ops(b, rew):
+    """N1: the oracle's merge against the very torch calls the reference makes (network.py:170-182)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    B, H, W, Q = 2, 5, 7, 3 * b * b + 27
+    bf = rng.standard_normal((B * H * W, Q)).astype(np.float32)
+    rgb_c = rng.standard_normal((B, 3, H * b, W * b)).astype(np.float32)
+    dep = rng.uniform(400, 900, (B * H * W,)).astype(np.float32)
+    opa = rng.uniform(0, 1, (B * H * W,)).astype(np.float32)
+    img, d, o = oracle.merge(bf, rgb_c, dep, opa, B, H, W, b, rew)
+    nerf_feat = torch.from_numpy(bf).view(B, H, W, -1).permute(0, 3, 1, 2)
+    rgb_f = F.pixel_shuffle(nerf_feat[:, :3 * b * b], b)
+    ref = torch.from_numpy(rgb_c) + rgb_f
+    if rew:
+        ref = 0.5 * (ref + rgb_f)
+    assert np.array_equal(img, ref.numpy())
+    up = lambda t: F.interpolate(torch.from_numpy(t).view(B, 1, H, W), scale_factor=b, mode="bilinear", align_corners=False).squeeze(1).numpy()
+    # same taps and weights; torch's CPU kernel may contract the weighted sums differently (2 ulp at |depth| ~ 900)
+    assert np.abs(d - up(dep)).max() <= 3e-7 * 900 and np.abs(o - up(opa)).max() <= 3e-7
