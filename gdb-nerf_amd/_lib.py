@@ -42,6 +42,7 @@ _SIGNATURES = {
     "gdb_packed_weight_floats": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
     "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),
+    "gdb_prepare_fpn": (C.c_int, [_CFG, _FRM, _P, _P, C.c_size_t, _P]),
     "gdb_build_rays": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P]),
     "gdb_sample": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdb_encode": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

@@ -67,7 +67,8 @@ int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs) {
         return gdb_fail(GDB_E_SHAPE, "bundle map %dx%d != image/bundle_size %dx%d", f->H, f->W, f->Ho / c->bundle_size, f->Wo / c->bundle_size);
     if ((size_t)f->B * f->H * f->W * c->max_num_samples >= (size_t)1 << 31)
         return gdb_fail(GDB_E_SHAPE, "more than 2^31 sample slots");
-    if (need_ptrs && (!f->d_src_images || !f->d_img_feat || !f->d_feat_volume || !f->d_depth_range || !f->d_vol_range ||
+    // (d_img_feat is read by gdb_prepare only: afterwards the feature pyramid in the workspace stands for it)
+    if (need_ptrs && (!f->d_src_images || !f->d_feat_volume || !f->d_depth_range || !f->d_vol_range ||
                       !f->d_src_exts || !f->d_src_ints || !f->d_tar_exts || !f->d_tar_ints || !f->d_near_far))
         return gdb_fail(GDB_E_BADARG, "frame has a NULL device pointer");
     return GDB_OK;
@@ -182,6 +183,7 @@ struct PrepArgs {
     unsigned lvlOff[GDB_MAX_MIP + 1];
     unsigned pyrStride;
     const float* img_feat; float* pyr;
+    const float* src_images; int Ho, Wo, fpn;  // fpn: img_feat holds C_f channels only; the 3 colours are resampled here (N3)
     const float* tar_exts; const float* tar_ints; const float* src_exts; const float* src_ints; const float* near_far;
     float* cams;
 };
@@ -207,10 +209,31 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
     const bool in0 = gx < a.W && gy < a.H;
-    const float* src = a.img_feat + (size_t)bv * GDB_CFR * a.H * a.W + (size_t)min(gy, a.H - 1) * a.W + min(gx, a.W - 1);
+    const int nch = a.fpn ? GDB_CF : GDB_CFR;  // channels in the input map
+    const float* src = a.img_feat + (size_t)bv * nch * a.H * a.W + (size_t)min(gy, a.H - 1) * a.W + min(gx, a.W - 1);
     float v[GDB_CP];
 #pragma unroll
-    for (int c = 0; c < GDB_CFR; ++c) v[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
+    for (int c = 0; c < GDB_CF; ++c) v[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
+    if (a.fpn) {
+        // network.py:159-164: the source image resampled to the bundle map, F.interpolate(mode='bilinear',
+        // align_corners=False): src = (dst + 0.5) * (n_in / n_out) - 0.5 (>= 0 here), taps i0, min(i0 + 1, n_in - 1)
+        const float sy = fmaxf(((float)min(gy, a.H - 1) + 0.5f) * ((float)a.Ho / (float)a.H) - 0.5f, 0.f);
+        const float sx = fmaxf(((float)min(gx, a.W - 1) + 0.5f) * ((float)a.Wo / (float)a.W) - 0.5f, 0.f);
+        const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+        const int y1 = min(y0 + 1, a.Ho - 1), x1 = min(x0 + 1, a.Wo - 1);
+        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* im = a.src_images + (size_t)bv * 3 * a.Ho * a.Wo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* pl = im + (size_t)c * a.Ho * a.Wo;
+            const float top = lx0 * pl[(size_t)y0 * a.Wo + x0] + lx1 * pl[(size_t)y0 * a.Wo + x1];
+            const float bot = lx0 * pl[(size_t)y1 * a.Wo + x0] + lx1 * pl[(size_t)y1 * a.Wo + x1];
+            v[GDB_CF + c] = in0 ? ly0 * top + ly1 * bot : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int c = GDB_CF; c < GDB_CFR; ++c) v[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
+    }
     v[GDB_CFR] = 0.f;
     float4* pyr4 = (float4*)(a.pyr + (size_t)bv * a.pyrStride);
 #pragma unroll
@@ -252,7 +275,19 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     }
 }
 
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, void* ws, size_t ws_bytes, void* stream_);
+
 extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
+    return prepare_common(cfg, f, nullptr, ws, ws_bytes, stream_);
+}
+
+extern "C" int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, void* ws, size_t ws_bytes, void* stream_) {
+    if (!d_fpn_feat) return gdb_fail(GDB_E_BADARG, "d_fpn_feat is NULL");
+    if (!f || !f->d_src_images) return gdb_fail(GDB_E_BADARG, "gdb_prepare_fpn resamples frame->d_src_images: it is NULL");
+    return prepare_common(cfg, f, d_fpn_feat, ws, ws_bytes, stream_);
+}
+
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, void* ws, size_t ws_bytes, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
     if (!ws) return gdb_fail(GDB_E_BADARG, "workspace is NULL");
@@ -267,11 +302,12 @@ extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, si
     a.B = f->B; a.V = f->V; a.H = f->H; a.W = f->W; a.levels = L.levels;
     if (a.levels > 3) return gdb_fail(GDB_E_BADARG, "max_mipmap_level > 3 unsupported by the tile kernel");
     a.tilesX = (f->W + PT_W - 1) / PT_W; a.tilesY = (f->H + PT_H - 1) / PT_H;
-    a.ntiles = f->d_img_feat ? a.tilesX * a.tilesY * f->B * f->V : 0;
+    a.ntiles = (f->d_img_feat || fpn_feat) ? a.tilesX * a.tilesY * f->B * f->V : 0;
     a.b = cfg->bundle_size; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { a.lvlH[i] = L.lvlH[i]; a.lvlW[i] = L.lvlW[i]; a.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     a.pyrStride = (unsigned)L.pyrStride;
-    a.img_feat = f->d_img_feat; a.pyr = (float*)((char*)ws + L.pyrOff);
+    a.img_feat = fpn_feat ? fpn_feat : f->d_img_feat; a.pyr = (float*)((char*)ws + L.pyrOff);
+    a.fpn = fpn_feat != nullptr; a.src_images = f->d_src_images; a.Ho = f->Ho; a.Wo = f->Wo;
     a.tar_exts = f->d_tar_exts; a.tar_ints = f->d_tar_ints; a.src_exts = f->d_src_exts; a.src_ints = f->d_src_ints;
     a.near_far = f->d_near_far; a.cams = (float*)((char*)ws + L.camsOff);
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1), dim3(256), 0, st, a);

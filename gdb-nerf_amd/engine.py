@@ -130,9 +130,16 @@ class HotPathEngine:
             raise ValueError(f"image {Ho}x{Wo} not divisible by bundle_size {b}")
         H, W = Ho // b, Wo // b
         dims = (B, V, Ho, Wo, H, W, D, self.cfg.feat_dim, self.cfg.voxel_dim)
+        fpn = frame.get("fpn_feat")  # N3: the FPN level alone, (B,V,C_f,H,W); the colour channels are resampled by the kernel
+        if fpn is not None:
+            if "img_feat" in frame:
+                raise ValueError("give img_feat (features + colours) or fpn_feat (features alone), not both")
+            _chk(fpn, "fpn_feat", (B, V, self.cfg.feat_dim, H, W))
         for name, shp in _FRAME_SHAPES.items():
             if name in frame:
                 _chk(frame[name], name, shp(*dims))
+            elif name == "img_feat" and fpn is not None:
+                continue
             elif "src_images" in frame or name in ("tar_ext", "tar_int", "near_far"):
                 raise KeyError(name)
         f = GdbFrame(B, V, Ho, Wo, H, W, D, *(_ptr(frame.get(k)) for k in (
@@ -143,7 +150,10 @@ class HotPathEngine:
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         self._frame, self._keep = f, dict(frame)
-        _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        if fpn is not None:
+            _lib.check(self.lib.gdb_prepare_fpn(C.byref(self.cfg), C.byref(f), fpn.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        else:
+            _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
 
     # ---- next row N1: merge around the decoder ------------------------------------------------
     def merge(self, bundle_feat, rgb_c=None, bundle_depth=None, bundle_opacity=None, reweighting: bool = False):

@@ -104,18 +104,18 @@ class Network(nn.Module):
         img_feat = ms_feats[self.feat_level]
         if img_feat.shape[-2:] != (H, W):
             img_feat = F.interpolate(img_feat.flatten(0, 1), size=(H, W), mode="bilinear", align_corners=False).unflatten(0, (B, V))
-        rgb_lo = F.interpolate(src_images.flatten(0, 1), size=(H, W), mode="bilinear", align_corners=False).unflatten(0, (B, V))
-        img_feat_rgb = torch.cat((img_feat, rgb_lo), dim=2)
-
         eng = None
         if self.hot_path == "fused":
             c = lambda t: t.contiguous().float()
             eng = self._get_engine(src_images.device)
-            eng.prepare({"src_images": c(src_images), "img_feat": c(img_feat_rgb), "feat_volume": c(feat_volume),
+            # N3: the kernel resamples the colour channels itself (no torch.cat / F.interpolate of the source images)
+            eng.prepare({"src_images": c(src_images), "fpn_feat": c(img_feat), "feat_volume": c(feat_volume),
                          "depth_range": c(depth_range), "vol_range": c(vol_range), "src_exts": c(src_exts), "src_ints": c(src_ints),
                          "tar_ext": c(tar_exts), "tar_int": c(tar_ints), "near_far": c(near_far)})
             bundle_feat, bundle_depth, bundle_opacity = eng.render()
         else:
+            rgb_lo = F.interpolate(src_images.flatten(0, 1), size=(H, W), mode="bilinear", align_corners=False).unflatten(0, (B, V))
+            img_feat_rgb = torch.cat((img_feat, rgb_lo), dim=2)
             self.sampler.build_rays(tar_exts, tar_ints, (Ho, Wo), near_far[:, 0], near_far[:, 1])
             rays_xyz, uvd, z_vals, ball_radii, indices, per_batch, per_bundle = self.sampler.sample(
                 depth_range, vol_range, b, self.max_num_samples, self.inv_depth, self.is_adaptive)

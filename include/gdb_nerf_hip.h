@@ -115,6 +115,12 @@ int gdb_pack_weights(const GdbConfig* cfg, const float* const h_tensors[18], flo
 int gdb_prepare(const GdbConfig* cfg, const GdbFrame* frame, void* d_workspace, size_t workspace_bytes,
                 void* stream);
 
+/* The same from the FPN output (next row N3): d_fpn_feat (B,V,C_f,H,W) is the feature level alone; the three colour
+ * channels the reference concatenates (network.py:159-164: F.interpolate(src_images, size=(H,W), mode='bilinear',
+ * align_corners=False)) are resampled from frame->d_src_images inside the same launch.  frame->d_img_feat is ignored. */
+int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, void* d_workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ---- operator mirrors (one per reference method) ------------------------------------ */
 /* BundleSampler.build_rays, bundle_sampler.py:30-74.  Needs gdb_prepare on the same
  * workspace first.  Outputs: d_rays_d (B,Ho,Wo,3), d_uv (Ho,Wo,2), d_rays_o (B,3),

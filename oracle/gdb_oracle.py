@@ -640,3 +640,33 @@ def merge(bundle_feat: np.ndarray, rgb_c: np.ndarray, bundle_depth: np.ndarray, 
     if reweighting:
         img = (F32(0.5) * (img + rgb_f)).astype(F32)
     return img, upsample_bilinear(_f(bundle_depth).reshape(B, H, W), b), upsample_bilinear(_f(bundle_opacity).reshape(B, H, W), b)
+
+
+# ----------------------------------------------------------------------------------------
+# N3  img_feat production: FPN features ⊕ source colours resampled to the bundle map    (network.py:159-164)
+# ----------------------------------------------------------------------------------------
+def resample_bilinear(x: np.ndarray, H: int, W: int) -> np.ndarray:
+    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=False) of (..., Hi, Wi) maps:
+    src = (dst + 0.5) * (n_in / n_out) - 0.5 clamped at 0, taps i0 = floor(src), i1 = min(i0 + 1, n_in - 1)."""
+    x = _f(x)
+    Hi, Wi = x.shape[-2:]
+
+    def taps(n_in, n_out):
+        src = np.maximum((np.arange(n_out, dtype=F32) + F32(0.5)) * F32(n_in / n_out) - F32(0.5), F32(0)).astype(F32)
+        i0 = np.floor(src).astype(np.int64)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(F32)).astype(F32)
+        return i0, i1, (F32(1) - l1).astype(F32), l1
+
+    y0, y1, ly0, ly1 = taps(Hi, H)
+    x0, x1, lx0, lx1 = taps(Wi, W)
+    top = (lx0 * x[..., y0, :][..., x0] + lx1 * x[..., y0, :][..., x1]).astype(F32)
+    bot = (lx0 * x[..., y1, :][..., x0] + lx1 * x[..., y1, :][..., x1]).astype(F32)
+    return (ly0[:, None] * top + ly1[:, None] * bot).astype(F32)
+
+
+def build_img_feat(fpn_feat: np.ndarray, src_images: np.ndarray) -> np.ndarray:
+    """network.py:159-164 (the branch where the FPN level already has the bundle map's size): concatenate the
+    (B,V,C_f,H,W) features with the source images resampled to (H,W) -> (B,V,C_f+3,H,W)."""
+    H, W = fpn_feat.shape[-2:]
+    return np.concatenate((_f(fpn_feat), resample_bilinear(src_images, H, W)), axis=2)

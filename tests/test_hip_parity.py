@@ -458,3 +458,27 @@ def test_merge_vs_oracle_and_torch(b, rew, B, Ho, Wo):
     assert d0 is None and o0 is None and np.array_equal(npy(img0), rgb_f.numpy())
     with pytest.raises(ValueError, match="bundle_feat"):
         eng.merge(t(bf)[:-1])
+
+
+@pytest.mark.parametrize("Ho,Wo,b,V,B", [(64, 80, 2, 3, 1), (96, 72, 2, 2, 2), (64, 96, 4, 2, 1), (40, 104, 2, 2, 1), (24, 40, 1, 2, 1)])
+def test_prepare_from_fpn_features(Ho, Wo, b, V, B):
+    """N3 (network.py:159-164): gdb_prepare_fpn builds the pyramid from the FPN level and the source images; the colour
+    channels must equal F.interpolate(src_images -> (H, W)) (oracle.build_img_feat), the rest the pyramid of gdb_prepare."""
+    frame = synthetic.make_frame(Ho, Wo, V=V, B=B, bundle_size=b, seed=19)
+    fpn = np.ascontiguousarray(frame["img_feat"][:, :, :16])
+    want_feat = oracle.build_img_feat(fpn, frame["src_images"])
+    eng = HotPathEngine(bundle_size=b)
+    d = dev_frame(frame)
+    d.pop("img_feat")
+    d["fpn_feat"] = torch.from_numpy(fpn).cuda()
+    eng.prepare(d)
+    got = eng.feature_pyramid()
+    for bi in range(B):
+        want = oracle.build_mips(np.transpose(want_feat[bi], (0, 2, 3, 1)), 3)
+        assert len(got) == len(want)
+        for l, w in enumerate(want):
+            g = npy(got[l][bi])
+            assert np.array_equal(g[..., :16].view(np.uint32), w[..., :16].view(np.uint32))   # features: pure data movement + exact averages
+            assert max_abs(g[..., 16:], w[..., 16:]) <= 3e-7                                     # colours: resampled in fp32
+    with pytest.raises(ValueError, match="not both"):
+        eng.prepare({**dev_frame(frame), "fpn_feat": d["fpn_feat"]})

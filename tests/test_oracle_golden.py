@@ -160,3 +160,19 @@ def test_merge_matches_torch_ops(b, rew):
     up = lambda t: F.interpolate(torch.from_numpy(t).view(B, 1, H, W), scale_factor=b, mode="bilinear", align_corners=False).squeeze(1).numpy()
     # same taps and weights; torch's CPU kernel may contract the weighted sums differently (2 ulp at |depth| ~ 900)
     assert np.abs(d - up(dep)).max() <= 3e-7 * 900 and np.abs(o - up(opa)).max() <= 3e-7
+
+
+@pytest.mark.parametrize("Ho,Wo,H,W", [(32, 48, 16, 24), (32, 48, 8, 12), (20, 28, 20, 28), (30, 42, 10, 14)])
+def test_build_img_feat_matches_torch_ops(Ho, Wo, H, W):
+    """N3: the oracle's feature ⊕ resampled-colour tensor against the torch calls of network.py:159-164."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(8)
+    B, V, Cf = 2, 3, 16
+    fpn = rng.standard_normal((B, V, Cf, H, W)).astype(np.float32)
+    src = rng.uniform(0, 1, (B, V, 3, Ho, Wo)).astype(np.float32)
+    got = oracle.build_img_feat(fpn, src)
+    ref = torch.cat((torch.from_numpy(fpn), F.interpolate(torch.from_numpy(src).flatten(0, 1), size=(H, W), mode="bilinear",
+                                                           align_corners=False).unflatten(0, (B, V))), dim=2).numpy()
+    assert got.shape == ref.shape and np.array_equal(got[:, :, :Cf], ref[:, :, :Cf])
+    assert np.abs(got - ref).max() <= 3e-7
