@@ -482,3 +482,22 @@ def test_prepare_from_fpn_features(Ho, Wo, b, V, B):
             assert max_abs(g[..., 16:], w[..., 16:]) <= 3e-7                                     # colours: resampled in fp32
     with pytest.raises(ValueError, match="not both"):
         eng.prepare({**dev_frame(frame), "fpn_feat": d["fpn_feat"]})
+
+
+@pytest.mark.parametrize("name,Ho,Wo,V,S,adaptive,scene", [("c3", 640, 960, 3, 3, True, "llff"), ("c4", 800, 800, 3, 6, True, "nerf"),
+                                                           ("c5", 1200, 1600, 5, 6, False, "dtu")])
+def test_fused_matches_fp32_chain_at_baseline_sizes(name, Ho, Wo, V, S, adaptive, scene, schedule):
+    """BASELINE.json configs[2..4] at full size (too big for the oracle in a test): fused kernel, both schedules, against
+    the fp32 operator chain (oracle-checked at small sizes above) + size-independent properties."""
+    frame = synthetic.make_frame(Ho, Wo, V=V, scene=scene, seed=1)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=0), max_num_samples=S, is_adaptive=adaptive)
+    bf, depth, opac = eng.render()
+    ubf, ud, uo = eng.render_unfused()
+    e = max_abs(npy(bf), npy(ubf))
+    print(f"{name} {Ho}x{Wo} V{V} S{S}: fused vs fp32 chain max abs err {e:.3e}")
+    assert e <= FUSED_TOL
+    assert max_abs(npy(opac), npy(uo)) <= 1e-5
+    assert max_abs(npy(depth), npy(ud)) <= 2e-3 * float(ud.abs().max())
+    assert float((opac - 1).abs().max()) <= 1e-5            # every bundle has samples: normalised weights sum to one
+    assert _psnr_delta(npy(bf), npy(ubf), Ho // 2, Wo // 2) <= 0.05
+    assert torch.equal(eng.render()[0], bf)                  # repeatable bit for bit
