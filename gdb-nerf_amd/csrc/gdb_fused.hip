@@ -182,8 +182,11 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 #else
 #define SKIPPED(skip, bit) false
 #endif
-constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND, STAGE_ROWS = NBLEND + 4;
-constexpr int STAGE_V = STAGE_ROWS * 32;     // 1120 floats = 4480 B
+// The 4 direction values are only ever an f16 MFMA operand: they are staged as two rows of packed halves (dir0|dir1,
+// dir2|dir3) - the same rounding, just earlier - which makes a view 33 rows: three views are 12,672 B, under the 12,800 B
+// at which twelve one-wave workgroups fit a CU (the LDS allocation granule is 1280 B: tools/ubench/simd_map.hip).
+constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND, STAGE_ROWS = NBLEND + 2;
+constexpr int STAGE_V = STAGE_ROWS * 32;     // 1056 floats = 4224 B
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
 constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
@@ -381,16 +384,15 @@ __device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, i
             int ch = 8 * s + 4 * h + e;
             t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
         }
-    float d[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = st[(ROW_DIR + e) * 32 + j];
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const unsigned* su = (const unsigned*)st;
+    const unsigned d01 = h == 0 ? su[(ROW_DIR + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(ROW_DIR + 1) * 32 + j] : 0u;
+    const half2v p01 = __builtin_bit_cast(half2v, d01), p23 = __builtin_bit_cast(half2v, d23);
 #pragma unroll
     for (int i = 0; i < 8; ++i) t.T0[i] = (_Float16)t.fv[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        t.T1[i] = (_Float16)t.fv[8 + i];                // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
-        t.T1[4 + i] = (_Float16)(h == 0 ? d[i] : 0.f);  // dir sits at tv[24..27], owned by half 0
-    }
+    for (int i = 0; i < 4; ++i) t.T1[i] = (_Float16)t.fv[8 + i];  // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
+    t.T1[4] = p01.x; t.T1[5] = p01.y; t.T1[6] = p23.x; t.T1[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
     t.T1[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
     return t;
 }
@@ -593,8 +595,11 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
         st[(ROW_FEAT + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
         if (h == 0) st[(ROW_FEAT + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
         if (h == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st[(ROW_DIR + e) * 32 + j] = dir[e];
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const half2v p01 = {(_Float16)dir[0], (_Float16)dir[1]}, p23 = {(_Float16)dir[2], (_Float16)dir[3]};
+            unsigned* su = (unsigned*)st;
+            su[(ROW_DIR + 0) * 32 + j] = __builtin_bit_cast(unsigned, p01);
+            su[(ROW_DIR + 1) * 32 + j] = __builtin_bit_cast(unsigned, p23);
         }
     }
 }

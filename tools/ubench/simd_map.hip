@@ -29,7 +29,14 @@ int main(int argc, char** argv) {
     int waves = argc > 1 ? atoi(argv[1]) : 3, lds = argc > 2 ? atoi(argv[2]) : 40320, wgs = argc > 3 ? atoi(argv[3]) : 1024;
     unsigned* d; CK(hipMalloc(&d, sizeof(unsigned) * 2 * wgs * waves));
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     k<<<wgs, waves * 64, lds>>>(d, 20000); CK(hipDeviceSynchronize());  // 200 us: every WG that fits is resident at once
+    CK(hipEventRecord(e0));
+    k<<<wgs, waves * 64, lds>>>(d, 20000);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("kernel time %.0f us for a 200 us spin: %.1f rounds -> at most %d workgroups resident per CU\n", ms * 1e3, ms * 1e3 / 200.0,
+           (int)((wgs + 255) / 256 / (int)(ms * 1e3 / 200.0 + 0.5)));
     std::vector<unsigned> h(2 * wgs * waves);
     CK(hipMemcpy(h.data(), d, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost));
     std::map<unsigned, std::array<int, 4>> per_cu;
