@@ -1,0 +1,33 @@
+"""One-off stress: N seeded random shapes x both schedules, fused kernel vs the fp32 operator chain (same checks as
+tests/test_hip_parity.py::test_fused_random_shapes_vs_fp32_chain).  usage: stress_fused.py [N] [seed]"""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from gdb_nerf_amd import synthetic
+from gdb_nerf_amd.engine import HotPathEngine
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+worst, bad = 0.0, 0
+for i in range(N):
+    Ho, Wo = 2 * int(rng.integers(4, 130)), 2 * int(rng.integers(4, 200))
+    c = dict(V=int(rng.integers(2, 9)), B=int(rng.integers(1, 4)), S=int(rng.integers(1, 17)), adaptive=bool(rng.integers(0, 2)),
+             inv=bool(rng.integers(0, 2)), levels=int(rng.integers(0, 4)), scene=["dtu", "llff", "nerf"][int(rng.integers(0, 3))],
+             fs=tuple(float(x) for x in rng.uniform(0.3, 8.0, size=3)))
+    frame = synthetic.make_frame(Ho, Wo, V=c["V"], B=c["B"], scene=c["scene"], seed=1000 + i, src_focal_scale=c["fs"])
+    eng = HotPathEngine(max_num_samples=c["S"], is_adaptive=c["adaptive"], inv_depth=c["inv"], max_mipmap_level=c["levels"])
+    eng.load_weights(synthetic.make_nerf_weights(seed=i))
+    eng.prepare({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in frame.items()})
+    ubf, ud, uo = [t.cpu().numpy() for t in eng.render_unfused()]
+    for sched in (1, 2):
+        eng.set_schedule(sched)
+        bf, d, o = [t.cpu().numpy() for t in eng.render()]
+        e = float(np.abs(bf - ubf).max()) if np.isfinite(bf).all() else float("inf")
+        eo = float(np.abs(o - uo).max())
+        worst = max(worst, e)
+        if not (e <= 2e-3 and eo <= 1e-5):
+            bad += 1
+            print(f"FAIL case {i} {Ho}x{Wo} {c} schedule {sched}: bundle_feat err {e:.3e}, opacity err {eo:.3e}", flush=True)
+    eng.set_schedule(0)
+    if i % 50 == 49: print(f"{i + 1} cases, worst err so far {worst:.3e}, failures {bad}", flush=True)
+print(f"done: {N} cases x 2 schedules, worst bundle_feat err {worst:.3e}, failures {bad}")
+sys.exit(1 if bad else 0)
