@@ -196,7 +196,7 @@ constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot 
 struct FusedArgs {
     DevFrame f;
     const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nsegs, ntiles, teams, alias, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
+    int row_begin, nrows, nseg, nsegs, ntiles, alias, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
     float* bf; float* depth; float* opac;
     unsigned* dbg;
 };
@@ -246,16 +246,11 @@ __device__ __forceinline__ T ldu_pin(const void* __restrict__ base, unsigned byt
     asm volatile("" : "+s"(b));
     return *(const T GLOBAL_AS*)(b + byte_off);
 }
-// GW: the weight section is in global memory (production) / in LDS (the GDB_FUSED_MODE=lds experiment)
-template <bool GW>
 __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off, int h) {
-    if (GW) return ldu_pin<f32x16>(mf + off, (unsigned)h * 64u);
-    return *(const f32x16*)(mf + off + h * 16);
+    return ldu_pin<f32x16>(mf + off, (unsigned)h * 64u);
 }
-template <bool GW>
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
-    if (GW) return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
-    return ((const half8*)(mf + (size_t)idx * 256))[lane];
+    return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
 }
 #define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
 // ReLU as exactly one instruction: written as fmaxf(x, 0) hipcc first canonicalises an MFMA output with v_max x, x, x
@@ -622,38 +617,33 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 
 // NeRF MLP (nerf.py:58-115) of one slot from its staged views; writes the slot's composite record.
 // `mf` = MFMA section of the packed weights, in global memory or (LDS-resident variant) in LDS.
-// VT > 0: the number of views is a compile-time constant, the view loops unroll and each view's operand
-// fragments (tail T0/T1, g_v) stay in registers across the three view passes; VT = 0: runtime V, fragments are
-// rebuilt from LDS in every pass.
+// The operand fragments of a view (tail T0/T1, g_v) are rebuilt from LDS in each of the three view passes: keeping them
+// in registers across the passes (a compile-time-V variant) needed 24 more VGPRs and spilled at 3 waves per SIMD.
 // Weight fragments are software-pipelined by hand across the phases: every phase first issues the loads of the NEXT
 // phase's fragments (they fly under this phase's MFMAs and VALU work), then computes with fragments loaded one phase
 // earlier.  The fences keep the compiler from moving the loads any further (hoisting all ~45 of them spills), so
 // without this each phase's first MFMA waits a full L2 round trip.
 // Outputs per lane (j, h): bacc[i] = blended channel 16h+i of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
 // channel 4h+i, sig = sigma pre-activation (valid in half 0).
-template <int VT, bool GW>
 __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const half8 H1, int lane, int j,
                                               int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
-    const int V = VT > 0 ? VT : f.V;
-    constexpr int NC = VT > 0 ? VT : 1, UNR = VT > 0 ? VT : 1;
-    half8 cT0[NC], cT1[NC], cG0[NC], cG1[NC];  // per-view fragment cache (VT > 0 only)
+    const int V = f.V;
     f32x16 base;
     half8 a_view, a_ga0, a_ga1;
     f32x16 w_agg;
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
-        a_view = load_frag<GW>(mf, F_VIEW, lane_o);
-        const half8 gv0 = load_frag<GW>(mf, F_GVAR, lane_o), gv1 = load_frag<GW>(mf, F_GVAR + 1, lane_o);
-        const half8 gm0 = load_frag<GW>(mf, F_GMEAN, lane_o), gm1 = load_frag<GW>(mf, F_GMEAN + 1, lane_o);
-        a_ga0 = load_frag<GW>(mf, F_GA, lane_o); a_ga1 = load_frag<GW>(mf, F_GA + 1, lane_o);  // next phase
-        w_agg = load_tab<GW>(mf, TD_AGG, h_o);
+        a_view = load_frag(mf, F_VIEW, lane_o);
+        const half8 gv0 = load_frag(mf, F_GVAR, lane_o), gv1 = load_frag(mf, F_GVAR + 1, lane_o);
+        const half8 gm0 = load_frag(mf, F_GMEAN, lane_o), gm1 = load_frag(mf, F_GMEAN + 1, lane_o);
+        a_ga0 = load_frag(mf, F_GA, lane_o); a_ga1 = load_frag(mf, F_GA + 1, lane_o);  // next phase
+        w_agg = load_tab(mf, TD_AGG, h_o);
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
-#pragma unroll UNR
+#pragma unroll 1
         for (int v = 0; v < V; ++v) {
             const Tail tl = load_tail(stage + (size_t)v * STAGE_V, j, h);
             f32x16 g = view_g(tl, a_view);
-            if (VT > 0) { cT0[v % NC] = tl.T0; cT1[v % NC] = tl.T1; cG0[v % NC] = acc_frag<0, false>(g); cG1[v % NC] = acc_frag<1, false>(g); }
             float inv = frcp((float)(v + 1));
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -677,19 +667,15 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     f32x16 agg, im;
     half8 fc0, fc1;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-        fc0 = load_frag<GW>(mf, F_FC, lane_o); fc1 = load_frag<GW>(mf, F_FC + 1, lane_o);  // next phase
-        im = load_tab<GW>(mf, TB_FC, h_o);
+        fc0 = load_frag(mf, F_FC, lane_o); fc1 = load_frag(mf, F_FC + 1, lane_o);  // next phase
+        im = load_tab(mf, TB_FC, h_o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         float mx = -INFINITY, den = 0.f;
-#pragma unroll UNR
+#pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            half8 g0, g1;
-            if (VT > 0) { g0 = cG0[v % NC]; g1 = cG1[v % NC]; }
-            else {
-                const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view);
-                g0 = acc_frag<0, false>(g); g1 = acc_frag<1, false>(g);
-            }
+            const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view);
+            const half8 g0 = acc_frag<0, false>(g), g1 = acc_frag<1, false>(g);
             f32x16 G = MFMA(a_ga0, g0, base);
             G = MFMA(a_ga1, g1, G);
             float sp = dot16_relu(G, w_agg);
@@ -708,8 +694,8 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     PHASE_FENCE();
     half8 H0, lr0, lr1, lr2, lr3;
     {   LANE_KEYS();  // im = fc(agg)   nerf.py:82
-        lr0 = load_frag<GW>(mf, F_LR0, lane_o); lr1 = load_frag<GW>(mf, F_LR0 + 1, lane_o);  // next phase
-        lr2 = load_frag<GW>(mf, F_LR0 + 2, lane_o); lr3 = load_frag<GW>(mf, F_LR0 + 3, lane_o);
+        lr0 = load_frag(mf, F_LR0, lane_o); lr1 = load_frag(mf, F_LR0 + 1, lane_o);  // next phase
+        lr2 = load_frag(mf, F_LR0 + 2, lane_o); lr3 = load_frag(mf, F_LR0 + 3, lane_o);
         im = MFMA(fc0, (acc_frag<0, false>(agg)), im);
         im = MFMA(fc1, (acc_frag<1, false>(agg)), im);
         H0 = acc_frag<0, true>(im);
@@ -718,8 +704,8 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     STAMP(4);
     half8 X00, X01, X10, X11, fhb, fh0, fh1, fh2, fh3;
     {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-        fhb = load_frag<GW>(mf, F_FHB, lane_o); fh0 = load_frag<GW>(mf, F_FH, lane_o); fh1 = load_frag<GW>(mf, F_FH + 1, lane_o);  // next phase
-        fh2 = load_frag<GW>(mf, F_FH + 2, lane_o); fh3 = load_frag<GW>(mf, F_FH + 3, lane_o);
+        fhb = load_frag(mf, F_FHB, lane_o); fh0 = load_frag(mf, F_FH, lane_o); fh1 = load_frag(mf, F_FH + 1, lane_o);  // next phase
+        fh2 = load_frag(mf, F_FH + 2, lane_o); fh3 = load_frag(mf, F_FH + 3, lane_o);
         f32x16 x0 = MFMA(lr0, H0, zero16());
         x0 = MFMA(lr1, H1, x0);
         X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
@@ -730,9 +716,9 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     PHASE_FENCE();
     half8 wa0, wa1, wa2, wa3, wb0, wb1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        wa0 = load_frag<GW>(mf, F_W0A + 0, lane_o); wa1 = load_frag<GW>(mf, F_W0A + 1, lane_o);  // next phase
-        wa2 = load_frag<GW>(mf, F_W0A + 2, lane_o); wa3 = load_frag<GW>(mf, F_W0A + 3, lane_o);
-        wb0 = load_frag<GW>(mf, F_W0B + 0, lane_o); wb1 = load_frag<GW>(mf, F_W0B + 1, lane_o);
+        wa0 = load_frag(mf, F_W0A + 0, lane_o); wa1 = load_frag(mf, F_W0A + 1, lane_o);  // next phase
+        wa2 = load_frag(mf, F_W0A + 2, lane_o); wa3 = load_frag(mf, F_W0A + 3, lane_o);
+        wb0 = load_frag(mf, F_W0B + 0, lane_o); wb1 = load_frag(mf, F_W0B + 1, lane_o);
         f32x16 fh = MFMA(fhb, H1, zero16());
         fh = MFMA(fh0, X00, fh);
         fh = MFMA(fh1, X01, fh);
@@ -747,9 +733,9 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     f32x16 hs0, hs1;
     half8 wc0, wc1, wc2, wc3, wd0, wd1;
     {   LANE_KEYS();
-        wc0 = load_frag<GW>(mf, F_W0A + 4, lane_o); wc1 = load_frag<GW>(mf, F_W0A + 5, lane_o);  // next phase
-        wc2 = load_frag<GW>(mf, F_W0A + 6, lane_o); wc3 = load_frag<GW>(mf, F_W0A + 7, lane_o);
-        wd0 = load_frag<GW>(mf, F_W0B + 2, lane_o); wd1 = load_frag<GW>(mf, F_W0B + 3, lane_o);
+        wc0 = load_frag(mf, F_W0A + 4, lane_o); wc1 = load_frag(mf, F_W0A + 5, lane_o);  // next phase
+        wc2 = load_frag(mf, F_W0A + 6, lane_o); wc3 = load_frag(mf, F_W0A + 7, lane_o);
+        wd0 = load_frag(mf, F_W0B + 2, lane_o); wd1 = load_frag(mf, F_W0B + 3, lane_o);
         hs0 = MFMA(wa0, X00, zero16());
         hs0 = MFMA(wa1, X01, hs0);
         hs0 = MFMA(wa2, X10, hs0);
@@ -762,9 +748,9 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     f32x16 w20, w21;
     {   LANE_KEYS();
         // operands of the per-view blend pass (next phase; loop-invariant there: loaded once per slot, not per view)
-        c00 = load_frag<GW>(mf, F_W0C + 0, lane_o); c01 = load_frag<GW>(mf, F_W0C + 1, lane_o);
-        c10 = load_frag<GW>(mf, F_W0C + 2, lane_o); c11 = load_frag<GW>(mf, F_W0C + 3, lane_o);
-        w20 = load_tab<GW>(mf, TD_W2, h_o); w21 = load_tab<GW>(mf, TD_W2 + 32, h_o);
+        c00 = load_frag(mf, F_W0C + 0, lane_o); c01 = load_frag(mf, F_W0C + 1, lane_o);
+        c10 = load_frag(mf, F_W0C + 2, lane_o); c11 = load_frag(mf, F_W0C + 3, lane_o);
+        w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o);
         hs1 = MFMA(wc0, X00, zero16());
         hs1 = MFMA(wc1, X01, hs1);
         hs1 = MFMA(wc2, X10, hs1);
@@ -779,12 +765,11 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
         float mx = -INFINITY, den = 0.f;
-#pragma unroll UNR
+#pragma unroll 1
         for (int v = 0; v < V; ++v) {
             const float* st = stage + (size_t)v * STAGE_V;
-            half8 T0, T1;
-            if (VT > 0) { T0 = cT0[v % NC]; T1 = cT1[v % NC]; }
-            else { const Tail t = load_tail(st, j, h); T0 = t.T0; T1 = t.T1; }
+            const Tail t = load_tail(st, j, h);
+            const half8 T0 = t.T0, T1 = t.T1;
             float up;
             {
                 f32x16 hv = MFMA(c00, T0, hs0);
@@ -822,11 +807,10 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
 __device__ __forceinline__ float alpha_of(float sig) { return frcp(1.f + __expf(-sig)); }
 
 // Workgroup-composite kernel: MLP of one slot, then the slot's composite record.
-template <int VT, bool GW>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
                                          const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
     float bacc[16], fhv[4], sig;
-    slot_mlp_core<VT, GW>(f, mf, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+    slot_mlp_core(f, mf, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -847,7 +831,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 // the segment's contiguous (32 x 39) block, depth and opacity (network.py:88-89).  SC > 0: S == SC at compile time.
 template <int SC>
 __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, size_t rec_stride, int S_rt, int tt, int tthreads,
-                                          bool has_seg, int seg, int row, int bi) {
+                                          int seg, int row, int bi) {
     const DevFrame& f = a.f;
     const int S = SC > 0 ? SC : S_rt;
     constexpr int NK = SC > 0 ? SC : 1;
@@ -879,7 +863,6 @@ __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, s
         }
     }
     __syncthreads();
-    if (!has_seg) return;
     const int nvalid = min(32, f.W - seg * 32);
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
     for (int qi = tt; qi < nvalid * NOUT; qi += tthreads) {
@@ -914,10 +897,11 @@ __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, s
     }
 }
 
-// Workgroup = `teams` segments x S sample slots (one wave per slot); LOOP: one segment, waves loop
-// over slots.  LDSW: the MFMA section of the weights is copied to LDS once per workgroup and shared.
-template <bool LDSW, bool LOOP, int WAVES, int VT>
-__global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 4) ? 2 : 3)) k_render_fused(FusedArgs a) {
+// Workgroup = one 32-bundle segment x S sample slots, one wave per slot; LOOP: fewer waves than slots, the waves loop
+// over slots.  The MLP weights come from global memory (L2-resident): an LDS-resident copy shared by a 9-12 wave
+// workgroup was measured 25-30 % slower (it caps the CU at 6-9 waves), see DESIGN.md.
+template <bool LOOP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     // the wave index is uniform but derived from threadIdx: without readfirstlane everything computed from it (team,
@@ -932,24 +916,19 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     const int chunk = (a.ntiles + 7) >> 3;
     const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (tile >= a.ntiles) return;  // whole workgroup leaves together
-    const int team = LOOP ? 0 : wid / S, k0 = LOOP ? wid : wid - team * S;
-    const int sg = tile * a.teams + team;
-    const bool has_seg = sg < a.nsegs;
-    const int sgc = min(sg, a.nsegs - 1);
-    const int seg = sgc % a.nseg, rr = sgc / a.nseg;
+    const int k0 = wid;
+    const int seg = tile % a.nseg, rr = tile / a.nseg;
     const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
     const int x = seg * 32 + j;
-    const bool inrow = has_seg && x < f.W;
+    const bool inrow = x < f.W;
 
-    // LDS: [weights (LDSW)] [per-wave staging V x STAGE_V] [composite records unless aliased].  With one
-    // slot per wave the record of slot k reuses wave k's own staging area, dead by then.
-    float* wl = smem;
-    const size_t wfl = LDSW ? (size_t)MFMA_FLOATS : 0;
+    // LDS: [per-wave staging V x STAGE_V] [composite records unless aliased].  With one slot per wave the record of
+    // slot k reuses wave k's own staging area, dead by then.
     const size_t wave_fl = (size_t)V * STAGE_V;
-    float* stage = smem + wfl + (size_t)wid * wave_fl;
+    float* stage = smem + (size_t)wid * wave_fl;
     const bool alias = a.alias != 0;
     const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
-    float* rec_team = alias ? smem + wfl + (size_t)team * S * wave_fl : smem + wfl + (size_t)nw * wave_fl + (size_t)team * S * COMP_REC;
+    float* rec_team = alias ? smem : smem + (size_t)nw * wave_fl;
     float rng[4];  // this lane's bundle ranges: issued first, the scalar loads below fly under their latency
     load_ranges(f, bi, row, min(x, f.W - 1), rng);
     float tc[TAR_STRIDE];  // target camera block of this wave's batch entry, in SGPRs
@@ -961,20 +940,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
     const float* mfg = a.pw + PW_FP32_FLOATS;
     const float b_agg = kptr(mfg)[TS_BAGG], b_w2 = kptr(mfg)[TS_BW2];  // the two scalar biases (agg_w_fc, weight.2)
 
-    if (LDSW) {  // copy the weight fragments / tables into LDS; visible after the barrier below
-        const float4* src = (const float4*)mfg;
-        for (int i = threadIdx.x; i < MFMA_FLOATS / 4; i += blockDim.x) ((float4*)wl)[i] = src[i];
-    }
     STAMP(0);
     if (LOOP) {
-        if (LDSW) __syncthreads();
         for (int k = k0; k < S; k += nw) {
             float* ck = rec_team + (size_t)k * rec_stride;
             bool act; float z; half8 H1;
             if (slot_gather(f, stage, ck, tc, rng, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!SKIPPED(a.skip, 8)) slot_mlp<VT, !LDSW>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+                if (!SKIPPED(a.skip, 8)) slot_mlp(f, mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
@@ -982,23 +956,22 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES > 8 ? 3 : ((LOOP || WAVES > 
         bool act; float z; half8 H1;
         const bool any = slot_gather(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, H1);
         STAMP(2);
-        if (LDSW) __syncthreads();
-        else { __builtin_amdgcn_wave_barrier(); PHASE_FENCE(); }
-        if (any && !SKIPPED(a.skip, 8)) slot_mlp<VT, !LDSW>(f, LDSW ? (const float*)wl : mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+        __builtin_amdgcn_wave_barrier();
+        PHASE_FENCE();
+        if (any && !SKIPPED(a.skip, 8)) slot_mlp(f, mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
     }
     STAMP(7);
     __syncthreads();
     STAMP(8);
-    const int tt = threadIdx.x - team * S * 64;  // thread index inside the team
-    const int tthreads = LOOP ? (int)blockDim.x : S * 64;
+    const int tt = threadIdx.x, tthreads = (int)blockDim.x;
     // The slot count is tiny: with it as a compile-time constant the S reads of a sum are all in flight before the first
     // is used (as a runtime loop every iteration waited for its own LDS read).
     switch (S) {
-        case 1: composite<1>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
-        case 2: composite<2>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
-        case 3: composite<3>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
-        case 4: composite<4>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
-        default: composite<0>(a, rec_team, rec_stride, S, tt, tthreads, has_seg, seg, row, bi); break;
+        case 1: composite<1>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        case 2: composite<2>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        case 3: composite<3>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        case 4: composite<4>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        default: composite<0>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
     }
     STAMP(9);
 }
@@ -1073,7 +1046,7 @@ __global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
         float bacc[16], fhv[4], sig;
-        slot_mlp_core<0, true>(f, mfg, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        slot_mlp_core(f, mfg, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
         const float sig0 = __shfl(sig, j);  // sigma sits in half 0
         if (act) {  // lanes without a sample hold unspecified MLP outputs: keep them out of the sums
             const float al = alpha_of(sig0);
@@ -1127,27 +1100,16 @@ static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hip
     return hipGetLastError();
 }
 
-template <bool LDSW, bool LOOP, int WAVES, int VT>
-static hipError_t launch_fused_v(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
+template <bool LOOP, int WAVES>
+static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LDSW, LOOP, WAVES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LOOP, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((k_render_fused<LDSW, LOOP, WAVES, VT>), dim3(grid), dim3(64 * nw), lds, st, a);
+    hipLaunchKernelGGL((k_render_fused<LOOP, WAVES>), dim3(grid), dim3(64 * nw), lds, st, a);
     return hipGetLastError();
-}
-// A compile-time 3-view specialisation (fragments cached in registers across the view passes) exists for the
-// global-weights, one-slot-per-wave shapes.  Measured on MI355X it gained 1.5 % before the loop-invariant weight
-// loads were hoisted and loses 3 % after (168 VGPRs + 9 spills vs 164 clean), so it is off unless GDB_FUSED_V3=1.
-template <bool LDSW, bool LOOP, int WAVES>
-static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
-    static const bool use_v3 = getenv("GDB_FUSED_V3") != nullptr;
-    if constexpr (!LDSW && !LOOP) {
-        if (a.f.V == 3 && use_v3) return launch_fused_v<LDSW, LOOP, WAVES, 3>(a, grid, nw, lds, st);
-    }
-    return launch_fused_v<LDSW, LOOP, WAVES, 0>(a, grid, nw, lds, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
@@ -1177,28 +1139,15 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.dbg = g_dbg;
-    // experiment switches, read once: GDB_FUSED_SKIP (timing-only ablation bits), GDB_FUSED_MODE=lds, GDB_FUSED_TEAMS
+    // experiment switches, read once: GDB_FUSED_SKIP (timing-only ablation bits, diagnostic build), GDB_FUSED_SOLO
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
-    static const bool env_lds = getenv("GDB_FUSED_MODE") && !strcmp(getenv("GDB_FUSED_MODE"), "lds");
-    static const int env_teams = getenv("GDB_FUSED_TEAMS") ? atoi(getenv("GDB_FUSED_TEAMS")) : 0;
     a.skip = env_skip;
     const int S = cfg->max_num_samples, V = fr->V;
-    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V, wbytes = sizeof(float) * (size_t)MFMA_FLOATS;
+    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
     const size_t lds_max = 160 * 1024;
     const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
-    // Weights stay in global memory (L2-resident) by default: measured on MI355X, 4 three-wave workgroups
-    // per CU (12 waves) beat every LDS-resident-weights shape (6..9 waves per CU) by 25-30 %.
-    // GDB_FUSED_MODE=lds selects the LDS-resident variant for experiments.
-    const bool allow_ldsw = env_lds;
     hipStream_t st = (hipStream_t)stream_;
     hipError_t e;
-    int teams = 0;
-    if (allow_ldsw && rec_fits && S <= 8) {  // LDS-resident weights, as many segments per workgroup as fit (<= 12 waves)
-        teams = 12 / S;
-        if (env_teams > 0) teams = env_teams;
-        while (teams > 0 && wbytes + (size_t)teams * S * per_wave > lds_max) --teams;
-        if ((size_t)teams > (size_t)a.nsegs) teams = a.nsegs;
-    }
     // Two schedules (gdb_fused_set_schedule; measured on MI355X, profiles/r01/schedules.txt):
     //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
     //                  nearly every slot holds a sample: S_max = 3 (c2 62 vs 72 us, c3 105 vs 126 us).
@@ -1208,22 +1157,15 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     const int sched = env_sched ? (env_sched[0] == '0' ? 1 : 2) : g_schedule;
     const bool want_solo = sched == 2 || (sched == 0 && S > 3);
     const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
-    if (want_solo && !allow_ldsw && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
-        a.teams = 1; a.alias = 0; a.ntiles = a.nsegs;
-        e = launch_solo(a, (unsigned)((a.ntiles + 7) / 8 * 8), solo_lds, st);
-    } else if (teams > 0) {
-        const int nw = teams * S;
-        a.teams = teams; a.alias = 1; a.ntiles = (a.nsegs + teams - 1) / teams;
-        const size_t lds = wbytes + (size_t)nw * per_wave;
-        const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-        if (nw <= 4) e = launch_fused<true, false, 4>(a, grid, nw, lds, st);
-        else if (nw <= 8) e = launch_fused<true, false, 8>(a, grid, nw, lds, st);
-        else e = launch_fused<true, false, 12>(a, grid, nw, lds, st);
-    } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one segment per workgroup, weights from global memory
-        a.teams = 1; a.alias = 1; a.ntiles = a.nsegs;
-        const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-        if (S <= 4) e = launch_fused<false, false, 4>(a, grid, S, (size_t)S * per_wave, st);
-        else e = launch_fused<false, false, 8>(a, grid, S, (size_t)S * per_wave, st);
+    a.ntiles = a.nsegs;
+    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
+        a.alias = 0;
+        e = launch_solo(a, grid, solo_lds, st);
+    } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot
+        a.alias = 1;
+        if (S <= 4) e = launch_fused<false, 4>(a, grid, S, (size_t)S * per_wave, st);
+        else e = launch_fused<false, 8>(a, grid, S, (size_t)S * per_wave, st);
     } else {  // more slots than waves fit: waves loop over slots, separate composite records
         const size_t fixed = sizeof(float) * (size_t)S * COMP_REC;
         int nw = S < 4 ? S : 4;
@@ -1231,8 +1173,8 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
         while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
         const size_t lds = fixed + nw * per_wave;
         if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
-        a.teams = 1; a.alias = 0; a.ntiles = a.nsegs;
-        e = launch_fused<false, true, 4>(a, (unsigned)((a.ntiles + 7) / 8 * 8), nw, lds, st);
+        a.alias = 0;
+        e = launch_fused<true, 4>(a, grid, nw, lds, st);
     }
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
     return GDB_OK;
