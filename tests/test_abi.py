@@ -100,3 +100,52 @@ def test_product_path_never_imports_oracle():
                 src = open(os.path.join(dirpath, fn), encoding="utf-8").read()
                 assert "gdb_oracle" not in src, fn
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (gcc, no C++), every declared entry point must be
+    addressable from C, the structs must have the layout ctypes assumes, and the library must link from a C program
+    (host-only calls: version, argument checking, packed-weight size — no GPU)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    hdr = open(os.path.join(ROOT, "include", "gdb_nerf_hip.h")).read()
+    names = sorted(set(re.findall(r"^(?:int|const char\*)\s+(gdb_\w+)\s*\(", hdr, flags=re.M)))
+    src = tmp_path / "abi.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include <stddef.h>
+#include "gdb_nerf_hip.h"
+int main(void) {
+    void (*fns[])(void) = {%s};
+    size_t i, n = 0;
+    GdbConfig c; GdbFrame f;
+    if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
+    for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
+    if (gdb_abi_version() != 1) return 12;
+    memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
+    c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
+    if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */
+    if (!strstr(gdb_last_error(), "power of 2")) return 14;
+    c.bundle_size = 2;
+    if (gdb_packed_weight_floats(&c, &n) != GDB_OK || n < 11930) return 15;
+    if (gdb_fused_set_schedule(7) != GDB_E_BADARG || gdb_fused_set_schedule(GDB_SCHED_AUTO) != GDB_OK) return 16;
+    printf("%%zu entry points, %%zu packed floats\\n", sizeof fns / sizeof fns[0], n);
+    return 0;
+}
+""" % ", ".join(f"(void (*)(void)){n}" for n in names))
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-l:libgdbnerf_hip.so", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    import torch  # the library's HIP runtime dependency resolves against the one torch ships
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert f"{len(names)} entry points" in r.stdout
