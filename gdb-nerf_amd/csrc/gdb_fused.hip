@@ -209,8 +209,6 @@ extern "C" int gdb_fused_set_schedule(int32_t mode) {
     return GDB_OK;
 }
 
-__device__ __forceinline__ float to_h_range(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
-
 // k-step S (0/1) of a 32x32 accumulator tile as the next layer's B operand (optionally through ReLU).
 template <int S, bool RELU>
 __device__ __forceinline__ half8 acc_frag(const f32x16& a) {
