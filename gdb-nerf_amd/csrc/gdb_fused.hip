@@ -430,7 +430,7 @@ __device__ __forceinline__ void view_dir_code(const float ctr[3], const float* _
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float* __restrict__ tc, float4 feat[3], float dir[4], float rgb[2][3], int skip) {
-    float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: 36 scalar loads, the block lives in SGPRs
+    float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: scalar loads (of the entries used below), the block lives in SGPRs
     {
         const kfloat* scg = kptr(src_cam(f, bi, v));
         asm volatile("" : "+s"(scg));  // not loop-invariant for the compiler: inside a slot loop LICM would hoist all V blocks
@@ -450,12 +450,12 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     float icz = frcp(cc[2]), ib = frcp(ball);
     float sec2 = d2 * icz * icz;
     float aa = fsqrt(fmaxf(d2 * ib * ib - 1.f, 1e-12f)), cq = fsqrt(fmaxf(sec2 - 1.f, 1e-12f));
-    float level = __builtin_amdgcn_logf(sec2 * frcp(aa + cq) * frcp(sc[S_PIXR]));  // v_log_f32 = log2
+    float level = __builtin_amdgcn_logf(sec2 * frcp(aa + cq) * sc[S_IPIXR]);  // v_log_f32 = log2
     float ci[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) ci[r] = fmaf(sc[S_KS + 3 * r], cc[0], fmaf(sc[S_KS + 3 * r + 1], cc[1], sc[S_KS + 3 * r + 2] * cc[2]));
     float izc = frcp(fmaxf(ci[2], 1e-6f));
-    float tu = ci[0] * izc * frcp((float)f.W), tvv = ci[1] * izc * frcp((float)f.H);   // :351-353
+    float tu = ci[0] * izc * f.invW, tvv = ci[1] * izc * f.invH;   // :351-353
     // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
@@ -470,12 +470,10 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     RgbTaps rt[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
-        float cm[3], im[3];
+        float im[3];  // K (E x + t) as one pre-multiplied 3x4 (S_P): 9 FMAs per point instead of 18
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            cm[r] = fmaf(sc[S_E + 4 * r], xyz[e][0], fmaf(sc[S_E + 4 * r + 1], xyz[e][1], fmaf(sc[S_E + 4 * r + 2], xyz[e][2], sc[S_E + 4 * r + 3])));
-#pragma unroll
-        for (int r = 0; r < 3; ++r) im[r] = fmaf(sc[S_K + 3 * r], cm[0], fmaf(sc[S_K + 3 * r + 1], cm[1], sc[S_K + 3 * r + 2] * cm[2]));
+            im[r] = fmaf(sc[S_P + 4 * r], xyz[e][0], fmaf(sc[S_P + 4 * r + 1], xyz[e][1], fmaf(sc[S_P + 4 * r + 2], xyz[e][2], sc[S_P + 4 * r + 3])));
         float iz = frcp(fmaxf(im[2], 1e-6f));
         rt[e] = rgb_taps(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
     }

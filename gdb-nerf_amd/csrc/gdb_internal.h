@@ -29,12 +29,14 @@
 #define T_FAR 17
 #define T_MINIV 18 // minimum sample interval         :227-229
 #define T_DISK 19  // b * pixel radius                :106
-#define SRC_STRIDE 36
+#define SRC_STRIDE 48
 #define S_E 0      // w2c rows 0..2 (3x4)
 #define S_K 12     // intrinsics 3x3
 #define S_KS 21    // intrinsics with rows 0,1 divided by b   :311-312
 #define S_C 30     // camera centre in world (3)              :305
 #define S_PIXR 33  // 1/sqrt(fx/b fy/b pi)                    :313
+#define S_IPIXR 34 // its reciprocal (fused kernel)
+#define S_P 35     // K * w2c rows 0..2 (3x4), product formed in fp64 (fused kernel: world -> pixel in one step)
 
 
 // ---- packed MLP weights, fp32 section (float offsets; every block 4-float aligned) --------
@@ -106,6 +108,7 @@ struct DevFrame {
     int lvlH[GDB_MAX_MIP + 1], lvlW[GDB_MAX_MIP + 1];
     unsigned lvlOff[GDB_MAX_MIP + 1];
     unsigned pyrStride;
+    float invW, invH;  // 1/W, 1/H of the bundle map (uniform reciprocals the fused kernel would otherwise recompute per view)
     const float* cams;
     const float* pyr;
     const float* src_images;
@@ -120,6 +123,7 @@ static inline DevFrame dev_frame(const GdbConfig& c, const GdbFrame& f, const Ws
     d.S_max = c.max_num_samples; d.adaptive = c.is_adaptive; d.inv_depth = c.inv_depth; d.levels = L.levels;
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { d.lvlH[i] = L.lvlH[i]; d.lvlW[i] = L.lvlW[i]; d.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     d.pyrStride = (unsigned)L.pyrStride;
+    d.invW = 1.f / (float)f.W; d.invH = 1.f / (float)f.H;
     d.cams = (const float*)((const char*)ws + L.camsOff);
     d.pyr = (const float*)((const char*)ws + L.pyrOff);
     d.src_images = f.d_src_images; d.feat_volume = f.d_feat_volume;

@@ -161,7 +161,14 @@ __device__ void cam_prep_one(int t, int B, int V, int b, int inv_depth, int gnd,
         for (int i = 0; i < 9; ++i) { s[S_K + i] = Kf[i]; s[S_KS + i] = (i < 6) ? Kf[i] / (float)b : Kf[i]; }
         for (int i = 0; i < 3; ++i) s[S_C + i] = (float)Ei[i * 4 + 3];
         s[S_PIXR] = 1.f / sqrtf(s[S_KS + 0] * s[S_KS + 4] * PI_F);
-        s[34] = 0.f; s[35] = 0.f;
+        s[S_IPIXR] = 1.f / s[S_PIXR];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += (double)Kf[3 * r + k] * (double)Ef[4 * k + c];
+                s[S_P + 4 * r + c] = (float)acc;
+            }
+        s[47] = 0.f;
     }
 }
 
