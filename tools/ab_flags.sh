@@ -13,7 +13,7 @@ for F in "$@"; do
   echo "[$F] tests: $(tail -1 gpurun_out/ab_tests_$i.log)"
   [ $rc -eq 0 ] || { grep -E "assert|Error|FAILED" gpurun_out/ab_tests_$i.log | head -5; i=$((i+1)); continue; }
   for r in 1 2 3; do
-    timeout -k 10 120 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$F]  G rays/s', round(d['value']/1e9,3), ' kernel us', round(d['roofline']['kernel_ms']*1e3,1))"
+    timeout -k 10 120 python bench.py --no-cpu-baseline ${AB_BENCH_ARGS:-} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$F]  G rays/s', round(d['value']/1e9,3), ' kernel us', round(d['roofline']['kernel_ms']*1e3,1))"
   done
   i=$((i+1))
 done
