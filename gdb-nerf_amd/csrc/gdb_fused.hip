@@ -1146,7 +1146,7 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     hipError_t e;
     // Two schedules (gdb_fused_set_schedule; measured on MI355X, profiles/r01/schedules.txt):
     //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
-    //                  nearly every slot holds a sample: S_max = 3 (c2 62 vs 72 us, c3 105 vs 126 us).
+    //                  most slots hold a sample: S_max = 3 (c2, 80 % of the lanes active: 62 vs 72 us; c3 105 vs 126 us).
     //  * segment wave - one wave walks all slots of its segment, composite in registers.  Best when slots are sparsely
     //                  filled or the S-wave workgroup is LDS-limited: c4 (S_max 6 adaptive) 171 vs 296 us, c5 1346 vs 1490 us.
     static const char* env_sched = getenv("GDB_FUSED_SOLO");  // experiment override: "0" slot waves, "1" segment wave
