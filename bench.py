@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the GDB-NeRF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2] [--path fused|unfused] [--shard frames|rows]
+    python bench.py --gpus N --steps K --warmup W [--workload c2] [--precision f32|f16] [--path fused|unfused]
 
-One *step* = one pass of the hot path (per-frame preparation: camera block + feature mip
-pyramid; then build_rays → sample → encode → MLP → composite) over one synthetic frame of
-the workload, inputs already resident in HBM.  Metric: rendered rays per second, whole job.
+One *step* = one pass of the hot path (per-frame preparation: camera block + feature mip pyramid; then
+build_rays → sample → encode → MLP → composite) over one synthetic frame of the workload, inputs already
+resident in HBM.  Metric: rendered rays per second, whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU):
-  --shard frames (default): every rank renders its own frame (independent target views, as an
-      evaluation sweep does); no data-path collective; weak scaling.
-  --shard rows: ONE frame, bundle-map row strips over the ranks, then an RCCL all-gather of
-      the rendered strips (north_star's single-frame latency mode); strong scaling.
+Headline (N = 1): workload c2 = BASELINE.json configs[1] at `--precision f32` — the NeRF MLP on fp32 MFMA, the
+reference's own precision (nerf.py:84-115 never leaves fp32).  The f16-operand path is timed in the same run and
+reported as the `secondary` record.  The JSON line also carries `psnr_delta_db` (fused render vs the exact-fp32
+operator chain on the benched frame), `hbm_frac` / `mfma_frac` against vendor peaks, `peaks_measured` (stream
+triad and bare MFMA loops run on this node), `t_frame_ms` (whole Network.forward, the reference's run.py:56-73
+protocol), `roofline` and `cpu_baseline`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at
-N = 1, `cpu_baseline` (the numpy oracle timed on this host's cores — a reported baseline,
-never part of the measured path).
+N > 1 (launched by torch.distributed.run, one rank per GPU), both modes timed in one run:
+  rows   (headline, north_star's partitioning, strong scaling): ONE frame, bundle-map row strips over the ranks,
+         packed (n_bundles, 41) output, a single RCCL all-gather of the strips; `allgather_ms` and bus GB/s reported.
+  frames (the `independent_frames` record, weak scaling): every rank renders its own frame (independent target
+         views, as an evaluation sweep does); no data-path collective.
+
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,17 +39,22 @@ sys.path.insert(0, ROOT)
 
 from gdb_nerf_amd import synthetic  # noqa: E402
 from gdb_nerf_amd.engine import HotPathEngine  # noqa: E402
-from gdb_nerf_amd.parallel import row_strip, gather_strips  # noqa: E402
+from gdb_nerf_amd.parallel import StripGather  # noqa: E402
 
 # BASELINE.json configs -> (Ho, Wo, V, S_max, adaptive, scene)
 WORKLOADS = {
     "c1": dict(Ho=64, Wo=80, V=3, S=3, adaptive=True, scene="dtu", desc="DTU-like 64x80 crop, 3 src views (CPU plumbing case)"),
     "c2": dict(Ho=512, Wo=640, V=3, S=3, adaptive=True, scene="dtu", desc="DTU eval 512x640, 3 src views, S_max 3 adaptive (configs/dtu_eval.yaml)"),
     "c3": dict(Ho=640, Wo=960, V=3, S=3, adaptive=True, scene="llff", desc="LLFF eval 640x960 (configs/llff_eval.yaml input_h_w)"),
+    "c3p": dict(Ho=756, Wo=1008, V=3, S=3, adaptive=True, scene="llff", desc="LLFF 756x1008 (BASELINE.json configs[2] literal size; synthetic upstream tensors)"),
     "c4": dict(Ho=800, Wo=800, V=3, S=6, adaptive=True, scene="nerf", desc="NeRF-synthetic eval 800x800, S_max 6 adaptive"),
     "c5": dict(Ho=1200, Wo=1600, V=5, S=6, adaptive=False, scene="dtu", desc="DTU full-res 1200x1600, 5 src views, S 6"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# vendor peaks (MI355X_MICROARCH.md): HBM3E 8 TB/s; dense matrix 2.5 PFLOP/s f16/bf16, 157.3 TFLOP/s f32-input MFMA
+HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}
+DTYPE = {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate (fetch / geometry / composite f32)"}
+PREC = {"f16": 0, "f32": 1}
 
 
 def alg_bytes(Ho, Wo, V, b=2, Cf=16, Cv=8, D=8, levels=3):
@@ -56,32 +67,148 @@ def alg_bytes(Ho, Wo, V, b=2, Cf=16, Cv=8, D=8, levels=3):
     return 4 * (V * 3 * Ho * Wo + V * (Cf + 3) * pyr + Cv * D * H * W + 4 * H * W + H * W * (Q + 2)) + 4 * 11930
 
 
+def alg_flops(n_samples, V):
+    """Algorithmic MLP flops: N_s (V * 18,200 + 5,248), the reference formulation (nerf.py:20-56),
+    N_s = the ACTUAL adaptive sample count of the frame."""
+    return float(n_samples) * (V * 18200 + 5248)
+
+
 def to_dev(frame, dev):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in frame.items()}
 
 
+def fine_rgb(bf, H, W):
+    """The pixel-shuffled fine RGB image of a render (network.py:170-175): (n_bundles, Q) -> (2H, 2W, 3)."""
+    x = bf[:, :12].reshape(H, W, 3, 2, 2)
+    return x.permute(0, 3, 1, 4, 2).reshape(2 * H, 2 * W, 3)
+
+
+def psnr_delta_db(bf, bf_ref, H, W):
+    """|PSNR(render, GT*) - PSNR(reference render, GT*)| with GT* = reference render + fixed noise (SURVEY.md §8(c):
+    no dataset offline); PSNR as the evaluator computes it (evaluators/gdb_nerf.py:78-82): clamp to [0,1], data range 1."""
+    a, b = fine_rgb(bf, H, W).double().cpu(), fine_rgb(bf_ref, H, W).double().cpu()
+    g = torch.Generator().manual_seed(0)
+    gt = (b + 0.03 * torch.randn(b.shape, generator=g, dtype=torch.float64)).clamp(0, 1)
+    ps = lambda x: 10.0 * torch.log10(1.0 / ((gt - x.clamp(0, 1)) ** 2).mean()).item()
+    return abs(ps(a) - ps(b))
+
+
+def measure_peaks(dev):
+    """Attainable peaks on this node: HBM stream triad over 3 x 256 MiB (beyond the 256 MiB Infinity
+    Cache) and bare MFMA loops (4 independent accumulators per wave, 2 waves per SIMD, operands in registers)."""
+    from gdb_nerf_amd import build as _b
+    lib = C.CDLL(_b.build_peaks())
+    lib.gdb_peak_triad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.gdb_peak_mfma.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n4 = (256 << 20) // 16
+    a, b, c = (torch.empty(n4 * 4, device=dev).normal_() for _ in range(3))
+    sink = torch.zeros(4096, device=dev)
+
+    def best(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1) * 1e-3)
+        return min(t)
+    t_triad = best(lambda: lib.gdb_peak_triad(a.data_ptr(), b.data_ptr(), c.data_ptr(), n4, st), 5)
+    blocks, iters = 2048, 2000
+    t32 = best(lambda: lib.gdb_peak_mfma(0, sink.data_ptr(), blocks, iters, st), 3)
+    t16 = best(lambda: lib.gdb_peak_mfma(1, sink.data_ptr(), blocks, 8 * iters, st), 3)
+    del a, b, c
+    return {"hbm_triad_GBps": 48.0 * n4 / t_triad / 1e9,
+            "mfma_f32_TFLOPs": blocks * 16 * iters * 4096 / t32 / 1e12,
+            "mfma_f16_TFLOPs": blocks * 16 * 8 * iters * 32768 / t16 / 1e12,
+            "how": "triad a=b+s*c on 3 x 256 MiB float4 arrays (best of 5); v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16 loops, "
+                   "2048 workgroups x 4 waves x 4 accumulators (best of 3)"}
+
+
 def cpu_baseline(wl, frame, weights):
-    """Time the oracle (CPU restatement of the reference path) on this host: whole frames of the
-    workload, repeated until about 10 s of CPU work has been done (never more than ~30 s)."""
+    """the CPU restatement of the hot path (the numpy oracle, checked against the reference's fixtures) on
+    this host's cores — all cores and an 8-thread row, 3 frames each, first dropped, mean of the rest."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gdb_oracle  # the checker, used here only as the reported CPU baseline
+    from threadpoolctl import threadpool_limits
 
+    model = "unknown"
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = 1
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ncpu = os.cpu_count() or 1
     Ho, Wo = wl["Ho"], wl["Wo"]
-    frames, t0 = 0, time.perf_counter()
-    while True:  # whole frames of the same workload until ~10 s of CPU work (bounded at 30 s)
-        gdb_oracle.hot_path(frame, weights, max_num_samples=wl["S"], is_adaptive=wl["adaptive"])
-        frames += 1
+    rows = []
+    for threads in (ncpu, 8):
+        with threadpool_limits(limits=threads):
+            torch.set_num_threads(threads)
+            t = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                gdb_oracle.hot_path(frame, weights, max_num_samples=wl["S"], is_adaptive=wl["adaptive"])
+                t.append(time.perf_counter() - t0)
+        rows.append({"threads": threads, "value": Ho * Wo / float(np.mean(t[1:])), "s_per_frame": float(np.mean(t[1:]))})
+    return {"value": rows[0]["value"], "unit": "rays/s", "cores": ncpu, "kind": "port", "cpu_model": model, "rows": rows,
+            "sample": f"3 full frames of {Ho}x{Wo} per row through the numpy float32 oracle (first dropped, mean of 2); BLAS matmuls "
+                      f"threaded to the row's thread count, element-wise numpy on one thread"}
+
+
+def frame_time_ms(dev):
+    """t_frame: whole Network.forward (CNNs on PyTorch-ROCm/MIOpen + the HIP hot path) on DTU eval 512x640, 3 views, random
+    init; the reference's protocol (run.py:56-73): synchronise, wall clock, drop the first iterations, mean."""
+    from gdb_nerf_amd.configs import make_cfg
+    from gdb_nerf_amd.networks import make_network
+    fr = synthetic.make_frame(512, 640, V=3, seed=0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
+             "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
+    torch.manual_seed(0)
+    net = make_network(make_cfg("configs/dtu_eval.yaml", [])).eval().to(dev)
+    times = []
+    with torch.no_grad():
+        for _ in range(14):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            net(batch)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    return 1e3 * float(np.mean(times[3:]))
+
+
+class Timed:
+    """K steps of `fn(sample)` bracketed by barrier + synchronize, max over ranks; `sample` is True on at most ~10 % of the
+    steps (and at least one), where fn records event pairs around the dominant kernel / the collective."""
+
+    def __init__(self, dist, dev, rehearse):
+        self.dist, self.dev, self.rehearse = dist, dev, rehearse
+
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, fn, warmup, steps):
+        for _ in range(warmup):
+            fn(False)
+        self.sync()
+        stride = max(10, steps // 100)
+        first = min(stride, steps) - 1
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i % stride == first)
+        self.sync()
         dt = time.perf_counter() - t0
-        if dt >= 10.0 or dt * (frames + 1) / frames > 30.0:
-            break
-    return {"value": frames * Ho * Wo / dt, "unit": "rays/s", "cores": int(cores), "kind": "port",
-            "sample": f"{frames} full frame(s) of {Ho}x{Wo} through the numpy float32 oracle in {dt:.1f} s "
-                      f"(BLAS matmuls on up to {cores} threads, element-wise parts on one)"}
+        if self.dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if self.rehearse else self.dev)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+
+def ev_ms(pairs):
+    return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else None
 
 
 def main():
@@ -92,12 +219,15 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run for this long before the W warm-up steps, so clocks have ramped (0 = off)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="arithmetic of the NeRF MLP in the fused kernel")
+    ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
-    ap.add_argument("--shard", default="frames", choices=["frames", "rows"])
+    ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary-precision record, PSNR, measured peaks and t_frame")
     ap.add_argument("--streams", type=int, default=1,
-                    help="fused path only: render consecutive (independent) frames on this many HIP streams with their own workspaces, "
-                         "so one frame's fill/drain overlaps the next; per-launch durations then overlap too (default 1)")
+                    help="fused path, N = 1 only: render consecutive (independent) frames on this many HIP streams with their own "
+                         "workspaces, so one frame's fill/drain overlaps the next; per-launch durations then overlap too (default 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,8 +237,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
-    # GDB_BENCH_REHEARSE=1: several ranks share the visible GPU(s) over gloo — a logic rehearsal of the
-    # N > 1 path on a one-GPU box, never a measurement.
+    # GDB_BENCH_REHEARSE=1: several ranks share the visible GPU(s) over gloo (collective staged through host memory) — a
+    # logic rehearsal of the N > 1 path on a one-GPU box, never a measurement.
     rehearse = os.environ.get("GDB_BENCH_REHEARSE") == "1"
     local = local % torch.cuda.device_count() if rehearse else local
     torch.cuda.set_device(local)
@@ -121,129 +251,210 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+    if args.streams > 1 and (args.path != "fused" or world > 1):
+        raise SystemExit("--streams > 1 is for the fused path at N = 1")
 
     wl = WORKLOADS[args.workload]
     Ho, Wo, V = wl["Ho"], wl["Wo"], wl["V"]
-    seed = rank if (world > 1 and args.shard == "frames") else 0  # rows mode: every rank holds the same frame
-    frame_np = synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=seed)
+    H, W = Ho // 2, Wo // 2
     weights_np = synthetic.make_nerf_weights(seed=0)
-    frame = to_dev(frame_np, dev)
-    if args.streams > 1 and (args.path != "fused" or (world > 1 and args.shard == "rows")):
-        raise SystemExit("--streams > 1 is for the fused path on independent frames")
-    H = Ho // 2
-    r0, r1 = row_strip(H, rank, world) if args.shard == "rows" else (0, H)
-    lanes = []  # one (engine, output buffers, stream) per stream; stream 0 is the current stream
-    for i in range(max(1, args.streams)):
+    prec = PREC[args.precision]
+
+    def make_engine(frame):
         e = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"], device=dev)
+        e.set_schedule(args.schedule)
+        e.precision = prec
         e.load_weights(weights_np)
         e.prepare(frame)
+        return e
+
+    frame_np = synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=0)  # rows mode: every rank holds the same frame
+    frame = to_dev(frame_np, dev)
+    timed = Timed(dist, dev, rehearse)
+    kern_pairs, ag_pairs = [], []
+
+    # ---- N = 1 (and each rank's whole-frame step) ------------------------------------------------------------------
+    lanes = []  # one (engine, output buffers, stream) per stream; stream 0 is the current stream
+    for i in range(max(1, args.streams)):
+        e = make_engine(frame)
         nb = e.n_bundles
         o = (torch.zeros((nb, e.Q), device=dev), torch.zeros((nb,), device=dev), torch.zeros((nb,), device=dev))
         lanes.append((e, o, torch.cuda.current_stream(dev) if i == 0 else torch.cuda.Stream(dev)))
     torch.cuda.synchronize()
     eng, out, _ = lanes[0]
     nb = eng.n_bundles
-
-    ev_pairs = []
     counter = [0]
 
-    def step(timed):
+    def events():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def step_frame(sample, precision=None, pairs=kern_pairs):
+        """prepare + hot path on this rank's whole frame."""
         if args.streams > 1:  # frame i on stream i % n: prepare + render back to back on that stream
             e, o, st = lanes[counter[0] % len(lanes)]
             counter[0] += 1
             with torch.cuda.stream(st):
                 e.prepare(frame)
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                e.render(r0, r1, 0, o)
-                if timed:
-                    e1.record()
-                    ev_pairs.append((e0, e1))
+                if sample:
+                    e0, e1 = events(); e0.record()
+                e.render(0, H, precision, o)
+                if sample:
+                    e1.record(); pairs.append((e0, e1))
             return
         eng.prepare(frame)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         if args.path == "fused":
-            eng.render(r0, r1, 0, out)
+            if sample:
+                e0, e1 = events(); e0.record()
+            eng.render(0, H, precision, out)
+            if sample:
+                e1.record(); pairs.append((e0, e1))
         else:
             s = eng.sample()
             rfd, vox = eng.encode(s["rays_xyz"], s["uvd"], s["ball_radii"], s["samples_per_batch"], s["total"])
-            if timed:  # dominant kernel of the unfused chain is the fp32 MLP
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            if sample:  # dominant kernel of the unfused chain is the fp32 MLP
+                e0, e1 = events(); e0.record()
             sigma, feat = eng.mlp(vox, rfd, s["total"])
-            if timed:
-                e1.record()
+            if sample:
+                e1.record(); pairs.append((e0, e1))
             eng.composite(sigma, feat, s["z_vals"], s["indices"], nb, s["total"])
-        if timed and args.path == "fused":
-            e1.record()
-        if timed:
-            ev_pairs.append((e0, e1))
-        if world > 1 and args.shard == "rows":
-            gather_strips(out[0], H, world, dist)
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # ---- N > 1, rows mode: one frame, row strips, packed output, one all-gather --------------------------------------
+    gather = None
+    if world > 1:
+        gather = StripGather(H, W, eng.Q + 2, world, rank, dev, dist, stage_cpu=rehearse)
+        r0, r1 = gather.strip
+
+    def step_rows(sample):
+        eng.prepare(frame)
+        if sample:
+            e0, e1 = events(); e0.record()
+        eng.render_packed(r0, r1, None, gather.full)
+        if sample:
+            e1.record(); kern_pairs.append((e0, e1))
+            a0, a1 = events(); a0.record()
+        gather.gather()
+        if sample:
+            a1.record(); ag_pairs.append((a0, a1))
 
     # clock ramp: a fresh process starts at idle clocks and a step is ~0.1 ms, so W warm-up steps alone can end before
     # the GPU reaches its sustained clock; run untimed steps for a fixed wall time first (not part of W or K)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for _ in range(20):
-            step(False)
+            step_frame(False)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step(False)
-    sync()
-    ev_stride = max(1, args.steps // 100)  # kernel-duration events on ~100 evenly spaced steps of the timed region
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i % ev_stride == 0)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
-    frames_per_step = world if (world > 1 and args.shard == "frames") else 1
-    rays_per_step = frames_per_step * Ho * Wo
+    rows_mode = world > 1 and args.shard == "rows"
+    extra = {}
+    if world == 1:
+        dt = timed.run(step_frame, args.warmup, args.steps)
+        rays_per_step, share = Ho * Wo, 1.0
+    else:
+        # both modes are timed; --shard picks the headline
+        dt_rows = timed.run(step_rows, args.warmup, args.steps)
+        kern_rows, ag_ms = ev_ms(kern_pairs), ev_ms(ag_pairs)
+        kern_pairs.clear()
+        # frames mode: every rank its own frame (seeded by rank)
+        frame = to_dev(synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=rank), dev)
+        dt_frames = timed.run(step_frame, args.warmup, args.steps)
+        kern_frames = ev_ms(kern_pairs)
+        rec_rows = {"mode": "rows: one frame, row strips, packed output, one all-gather", "scaling": "strong",
+                    "value": Ho * Wo * args.steps / dt_rows, "ms_per_step": dt_rows / args.steps * 1e3, "kernel_ms": kern_rows,
+                    "allgather_ms": ag_ms, "allgather_bytes_per_rank": gather.nbytes,
+                    "bus_GBps": (gather.nbytes / (ag_ms * 1e-3) / 1e9) if ag_ms else None,
+                    "collective": "gloo (rehearsal, staged through host memory)" if rehearse else "RCCL all_gather_into_tensor, in place" if gather.even else "RCCL all_gather_into_tensor, padded",
+                    "world_size": world}
+        rec_frames = {"mode": "frames: every rank its own frame, no data-path collective", "scaling": "weak",
+                      "value": world * Ho * Wo * args.steps / dt_frames, "ms_per_step": dt_frames / args.steps * 1e3, "kernel_ms": kern_frames}
+        if rows_mode:
+            dt, rays_per_step, share = dt_rows, Ho * Wo, (r1 - r0) / H
+            kern_pairs.clear()
+            extra.update({k: rec_rows[k] for k in ("allgather_ms", "allgather_bytes_per_rank", "bus_GBps", "collective", "world_size")})
+            extra["independent_frames"] = rec_frames
+            kern_ms_override = kern_rows
+        else:
+            dt, rays_per_step, share = dt_frames, world * Ho * Wo, 1.0
+            extra["single_frame_rows"] = rec_rows
+            kern_ms_override = kern_frames
+
+    kern_ms = ev_ms(kern_pairs) if world == 1 else kern_ms_override
     ms_per_step = dt / args.steps * 1e3
     value = rays_per_step * args.steps / dt
 
-    # roofline of the dominant kernel (per launch, this rank)
-    share = (r1 - r0) / H
+    # ---- roofline of the dominant kernel (per launch, this rank) -------------------------------------------------------
+    n_samples = int(eng.sample()["total"].item())  # actual adaptive sample count of the frame (operator mirror, untimed)
     ab = alg_bytes(Ho, Wo, V) * share
+    af = alg_flops(n_samples, V) * share
     if args.path == "fused":
-        kname = "k_render_fused"
+        kname = "k_render_fused" if (args.schedule == 1 or (args.schedule == 0 and wl["S"] <= 3)) else "k_render_solo"
     else:
         kname = "k_mlp"
-        ns = int(eng.sample()["total"].item())
-        ab = 4.0 * ns * (V * eng.P + 8 + 1 + eng.Q) + 4 * 11930  # what that kernel must read + write
-    achieved = ab / (kern_ms * 1e-3) / 1e9
-    traffic = None
+        ab = 4.0 * n_samples * (V * eng.P + 8 + 1 + eng.Q) + 4 * 11930  # what that kernel must read + write
+    pname = args.precision if args.path == "fused" else "f32"
+    hbm_gbs = ab / (kern_ms * 1e-3) / 1e9
+    mfma_tf = af / (kern_ms * 1e-3) / 1e12
+    hbm_frac, mfma_frac = hbm_gbs / HBM_PEAK_GBS, mfma_tf / MFMA_PEAK_TFLOPS[pname]
+    traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{args.workload}:{kname}")
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"{args.workload}:{kname}:{pname}")
+            tsrc = tj.get("_source")
         except Exception:
             traffic = None
+    # Which roofline bounds the kernel (SURVEY.md §8(d)): the larger of the two floors.  At fp32 the MLP's algorithmic flops
+    # against the 157 TFLOP/s fp32 matrix peak is the longer floor (c2: 74 us vs 9 us of HBM time); with f16 operands
+    # (2.5 PFLOP/s) the HBM floor is.
+    if args.path == "fused" and mfma_frac >= hbm_frac:
+        roof = {"bound": "mfma", "kernel": kname, "achieved": mfma_tf, "peak": MFMA_PEAK_TFLOPS[pname], "unit": "TFLOP/s", "frac": mfma_frac}
+    else:
+        roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
+    roof.update({"traffic": traffic, "traffic_source": tsrc, "kernel_ms": kern_ms, "alg_bytes": ab, "alg_flops": af, "n_samples": n_samples,
+                 "note": "achieved = ALGORITHMIC bytes / flops (SURVEY.md §8(d)) per launch / mean launch duration from HIP events on sampled steps"})
+
     res = {
         "metric": "rendered rays/sec, GDB-NeRF hot path (sample+fetch+MLP+composite)", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong" if (world > 1 and args.shard == "rows") else "weak",
-        "vs_baseline": None, "dtype": "f32 fetch/composite, f16 MFMA MLP (f32 accumulate)" if args.path == "fused" else "f32",
-        "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if rows_mode else "weak",
+        "vs_baseline": None, "dtype": DTYPE[pname], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
-                   "path": args.path, "shard": args.shard if world > 1 else "none", "prewarm_ms": args.prewarm_ms, "streams": args.streams},
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "alg_bytes": ab},
+                   "path": args.path, "precision": pname, "schedule": args.schedule, "shard": args.shard if world > 1 else "none",
+                   "prewarm_ms": args.prewarm_ms, "streams": args.streams},
+        "t_hot_ms": ms_per_step, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
+        "roofline": roof,
     }
+    res.update(extra)
+
+    if rank == 0 and world == 1 and not args.no_extras and args.path == "fused" and args.streams == 1:
+        # PSNR of the benched frame's render against the exact-fp32 operator chain (north_star: within 0.05 dB)
+        ubf = eng.render_unfused()[0]
+        eng.prepare(frame)
+        res["psnr_delta_db"] = psnr_delta_db(eng.render(0, H, prec)[0], ubf, H, W)
+        res["max_abs_err_vs_fp32_chain"] = float((eng.render(0, H, prec)[0] - ubf).abs().max())
+        # the other precision, timed the same way on the same frame (shorter region)
+        other = "f16" if args.precision == "f32" else "f32"
+        pairs2 = []
+        k2 = max(20, min(args.steps, 1000))
+        dt2 = timed.run(lambda s: step_frame(s, PREC[other], pairs2), min(args.warmup, 100), k2)
+        km2 = ev_ms(pairs2)
+        res["secondary"] = {"dtype": DTYPE[other], "precision": other, "value": Ho * Wo * k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
+                            "steps": k2, "kernel_ms": km2, "hbm_frac": ab / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "mfma_frac": af / (km2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[other],
+                            "psnr_delta_db": psnr_delta_db(eng.render(0, H, PREC[other])[0], ubf, H, W)}
+        del ubf
+        try:
+            pk = measure_peaks(dev)
+            pk["hbm_frac_of_measured"] = hbm_gbs / pk["hbm_triad_GBps"]
+            pk["mfma_frac_of_measured"] = mfma_tf / pk[f"mfma_{pname}_TFLOPs"]
+            res["peaks_measured"] = pk
+        except Exception as ex:  # measurement extras never take the headline down
+            res["peaks_measured"] = {"error": repr(ex)}
+        try:
+            res["t_frame_ms"] = frame_time_ms(dev)
+        except Exception as ex:
+            res["t_frame_ms"] = None
+            res["t_frame_error"] = repr(ex)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl, frame_np, weights_np)
     if rank == 0:

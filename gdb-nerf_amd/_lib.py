@@ -9,7 +9,12 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgdbnerf_hip.so")
+# GDB_NERF_LIB selects another build of the same ABI (tools/: the -DGDB_DIAG diagnostic library and A/B flag variants are
+# built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
+LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
+ABI_VERSION = 2
+PREC_F16, PREC_F32 = 0, 1
+SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE = 0, 1, 2
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8
@@ -52,8 +57,8 @@ _SIGNATURES = {
     "gdb_accumulate": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "gdb_build_feature_volume": (C.c_int, [_P] * 6 + [C.c_int32] * 9 + [_P, _P, _P]),
     "gdb_depth_regression": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
-    "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    "gdb_fused_set_schedule": (C.c_int, [C.c_int32]),
+    "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "gdb_render_bundles_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gdb_merge": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
@@ -76,8 +81,8 @@ def load() -> C.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.gdb_abi_version() != 1:
-            raise GdbError(f"ABI version {lib.gdb_abi_version()} != 1")
+        if lib.gdb_abi_version() != ABI_VERSION:
+            raise GdbError(f"ABI version {lib.gdb_abi_version()} != {ABI_VERSION}")
         _lib = lib
     return _lib
 

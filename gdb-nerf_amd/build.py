@@ -1,6 +1,15 @@
-"""Build libgdbnerf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libgdbnerf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python gdb-nerf_amd/build.py [--force] [--tag NAME --extra "FLAGS"]
+
+The product library is `libgdbnerf_hip.so`.  Diagnostic / experiment variants (extra compiler flags, e.g. -DGDB_DIAG for
+the stamp and ablation build) are written beside it as `libgdbnerf_hip.<tag>.so` with their own object directory and
+never replace the product library; select one with the environment variable GDB_NERF_LIB (see _lib.py).
+`libgdbpeaks.so` holds the attainable-peak micro-benchmarks bench.py runs (tools/ubench/peaks.hip) — measurement only.
+"""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -8,35 +17,51 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdbnerf_hip.so")
+PEAKS_SRC = os.path.join(HERE, "..", "tools", "ubench", "peaks.hip")
+PEAKS_LIB = os.path.join(HERE, "libgdbpeaks.so")
 SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip", "gdb_merge.hip")
-# -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 mul/add into v_pk_*_f32 with op_sel
-# modifiers; in the fused kernel that produced stale values in lanes 48..63 of one packed result
-# whenever two or more workgroups shared a CU (run-to-run different bundles, found with
-# tools/dbg_fused.py; gone with one workgroup per CU or without packing).  Packed f32 math is no
-# faster beside MFMA (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), so it is off.
+# -fno-slp-vectorize: packed f32 VALU (v_pk_*_f32) beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md,
+# "price of one filler beside MFMAs": +22..26 cycles per packed op) and hipcc's SLP pass packs adjacent f32 mul/add
+# under plain -O3; DESIGN.md §4.1 has the history of the stale-lane corruption first seen with it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
 # the fused fast path lets the compiler contract.
 CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off"}
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def lib_path(tag: str = "") -> str:
+    return LIB if not tag else os.path.join(HERE, f"libgdbnerf_hip.{tag}.so")
+
+
+def _flag_stamp(extra) -> str:
+    return hashlib.sha1(" ".join([*FLAGS, *extra, *sorted(f"{k}={v}" for k, v in CONTRACT.items())]).encode()).hexdigest()
+
+
+def _stale(lib: str, stamp_file: str, stamp: str) -> bool:
+    if not os.path.exists(lib) or not os.path.exists(stamp_file) or open(stamp_file).read().strip() != stamp:
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "gdb_nerf_hip.h"), __file__]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(HERE, "..", "include", "gdb_nerf_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def build(force: bool = False, verbose: bool = False, tag: str = "", extra=()) -> str:
+    """Build the library (tag "" = product flags only; the product build ignores the environment)."""
+    extra = list(extra)
+    if tag == "" and extra:
+        raise ValueError("extra flags need a tag: the product library is always built with the default flags")
+    lib = lib_path(tag)
+    objdir = os.path.join(CSRC, "obj" + ("." + tag if tag else ""))
+    stamp_file, stamp = os.path.join(objdir, "flags.sha1"), _flag_stamp(extra)
+    if not force and not _stale(lib, stamp_file, stamp):
+        return lib
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
+    objs, procs = [], []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *os.environ.get("GDB_HIPCC_EXTRA", "").split(), f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *extra, f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -47,12 +72,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB
+    with open(stamp_file, "w") as f:
+        f.write(stamp + "\n")
+    return lib
+
+
+def build_peaks(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(PEAKS_LIB) and os.path.getmtime(PEAKS_LIB) >= os.path.getmtime(PEAKS_SRC):
+        return PEAKS_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", PEAKS_SRC, "-o", PEAKS_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on peaks.hip:\n{r.stdout}")
+    return PEAKS_LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    extra = argv[argv.index("--extra") + 1].split() if "--extra" in argv else []
+    print(build(force="--force" in argv, verbose=True, tag=tag, extra=extra))
+    if not tag:
+        print(build_peaks(force="--force" in argv, verbose=True))

@@ -30,6 +30,7 @@ int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs);
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- MFMA section of the packed weights ---------------------------------------------------------
 // 33 A-operand fragments (64 lanes x 8 halfs = 256 floats each), then fp32 tables.
@@ -60,7 +61,33 @@ enum {
     MFMA_FLOATS = (TS_BW2 + 1 + 63) / 64 * 64
 };
 
-size_t gdb_mfma_section_floats() { return MFMA_FLOATS; }
+// ---- f32-MFMA section of the packed weights (precision GDB_PREC_F32), appended to the f16 section ---------------
+// v_mfma_f32_32x32x2_f32 takes ONE f32 per lane for A and for B: lane (i = l & 31, h = l >> 5) supplies A[i][k = h]
+// and B[k = h][j = i]; C/D use the 32x32 accumulator map.  So an accumulator register r of a finished layer IS a B
+// operand: it carries features acc_row(r, 0) (half 0) and acc_row(r, 1) (half 1) of the lane's sample, and the next
+// layer runs one MFMA per register with no conversion and no lane movement.  A "step" is one MFMA's A operand (64
+// floats, W[out row i][k of (step, h)]); four consecutive steps are stored as one float4 per lane (a "quad", 1 KiB).
+enum {
+    Q_VIEW = 0,    // view_fc on dir: 2 steps (step s carries dir 2s + h)
+    Q_GVAR = 1,    // global_fc columns [19,38) on var: 12 steps (register r of the 19-vector in accumulator layout)
+    Q_GMEAN = 4,   // global_fc columns [38,57) on mean
+    Q_GA = 7,      // global_fc columns [0,19) on g_v
+    Q_FC = 10,     // fc on the aggregated 32-vector: 16 steps
+    Q_LR0 = 14,    // [out tile 2][3 quads]: 8 steps on im (registers 0..7), then 4 on vox (step i carries channel i + 4h)
+    Q_FH = 20,     // rows 0..7 feat_head, row 8 sigma: 32 steps on x ([x tile][register])
+    Q_W0A = 28,    // weight.0 columns [0,64) on x: [out tile 2][8 quads]
+    Q_W0B = 44,    // weight.0 columns [64,88) on [vox | im]: [out tile 2][3 quads], step order as Q_LR0
+    Q_W0C = 50,    // weight.0 columns [88,111) on the per-view tail: [out tile 2][4 quads]: 12 steps on feat ⊕ rgb, 2 on dir
+    NQUADS = 58
+};
+enum {  // fp32 tables in accumulator layout [h][16] (bias tables initialise a layer's accumulator), then scalars
+    T32_VIEW = NQUADS * 256, T32_GLOB = T32_VIEW + 32, T32_FC = T32_GLOB + 32, T32_LR0 = T32_FC + 32 /* 2 tiles */,
+    T32_FH = T32_LR0 + 64, T32_W0 = T32_FH + 32 /* 2 tiles */, T32_AGG = T32_W0 + 64, T32_W2 = T32_AGG + 32 /* 2 tiles */,
+    S32_BAGG = T32_W2 + 64, S32_BW2 = S32_BAGG + 1,
+    F32SEC_FLOATS = (S32_BW2 + 1 + 63) / 64 * 64
+};
+
+size_t gdb_mfma_section_floats() { return (size_t)MFMA_FLOATS + F32SEC_FLOATS; }
 
 // Accumulator row of (register r, half h) in a 32x32 MFMA tile; also the k index that element
 // (r & 7) of k-step (r >> 3) carries when the tile is reused as a B operand.
@@ -157,6 +184,63 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
     p.table(TD_AGG, PW_AGG_W, 1, lt(GDB_GF));
     out[TS_BAGG] = fp32[PW_AGG_B];
     out[TS_BW2] = fp32[PW_W2_B];
+
+    // ---- f32-MFMA section ----------------------------------------------------------------------------------------
+    float* sec = out + MFMA_FLOATS;
+    memset(sec, 0, sizeof(float) * F32SEC_FLOATS);
+    Packer p32{fp32, sec};
+    // step `st` counted from quad q0: element (st & 3) of quad q0 + (st >> 2); kcol(h) -> column of W or -1
+    auto step = [&](int q0, int st, int wOff, int ld, auto rowmap, auto kcol) {
+        for (int l = 0; l < 64; ++l) {
+            int i = l & 31, h = l >> 5, orow = rowmap(i), col = kcol(h);
+            sec[(size_t)(q0 + (st >> 2)) * 256 + l * 4 + (st & 3)] = (orow >= 0 && col >= 0) ? fp32[wOff + orow * ld + col] : 0.f;
+        }
+    };
+    auto c19k = [](int r, int base) { return [=](int h) { int k = acc_row(r, h); return k < GDB_CFR ? base + k : -1; }; };
+    for (int s = 0; s < 2; ++s) step(Q_VIEW, s, PW_VIEW_W, 4, lt(GDB_CFR), [=](int h) { return 2 * s + h; });
+    for (int r = 0; r < 12; ++r) {
+        step(Q_GVAR, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, GDB_CFR));
+        step(Q_GMEAN, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, 2 * GDB_CFR));
+        step(Q_GA, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, 0));
+    }
+    for (int r = 0; r < 16; ++r) step(Q_FC, r, PW_FC_W, GDB_GF, lt(GDB_IM), [=](int h) { return acc_row(r, h); });
+    // [vox | im] operand: steps 0..7 = im registers (features acc_row(r, h) < 16), steps 8..11 = vox channel i + 4h
+    auto hk = [](int st, int base) {
+        return [=](int h) { return st < 8 ? base + GDB_CV + acc_row(st, h) : base + (st - 8) + 4 * h; };
+    };
+    for (int ot = 0; ot < 2; ++ot) {
+        for (int st = 0; st < 12; ++st) {
+            step(Q_LR0 + 3 * ot, st, PW_LR0_W, GDB_HD, tile(ot, GDB_HID), hk(st, 0));
+            step(Q_W0B + 3 * ot, st, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), hk(st, GDB_HID));
+        }
+        for (int st = 0; st < 32; ++st)
+            step(Q_W0A + 8 * ot, st, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h) { return 32 * (st >> 4) + acc_row(st & 15, h); });
+        for (int r = 0; r < 12; ++r) step(Q_W0C + 4 * ot, r, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), c19k(r, GDB_HID + GDB_HD));
+        for (int s = 0; s < 2; ++s)
+            step(Q_W0C + 4 * ot, 12 + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h) { return GDB_HID + GDB_HD + GDB_CFR + 2 * s + h; });
+    }
+    for (int st = 0; st < 32; ++st)  // rows 0..7 feat_head, row 8 sigma
+        for (int l = 0; l < 64; ++l) {
+            int i = l & 31, h = l >> 5, col = 32 * (st >> 4) + acc_row(st & 15, h);
+            sec[(size_t)(Q_FH + (st >> 2)) * 256 + l * 4 + (st & 3)] =
+                i < GDB_CV ? fp32[PW_FH_W + i * GDB_HID + col] : (i == GDB_CV ? fp32[PW_SIG_W + col] : 0.f);
+        }
+    p32.table(T32_VIEW, PW_VIEW_B, 1, lt(GDB_CFR));
+    p32.table(T32_GLOB, PW_GLOB_B, 1, lt(GDB_GF));
+    p32.table(T32_FC, PW_FC_B, 1, lt(GDB_IM));
+    for (int ot = 0; ot < 2; ++ot) {
+        p32.table(T32_LR0 + 32 * ot, PW_LR0_B, 1, tile(ot, GDB_HID));
+        p32.table(T32_W0 + 32 * ot, PW_W0_B, 1, tile(ot, GDB_HID));
+        p32.table(T32_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+            int o = acc_row(r, h);
+            sec[T32_FH + h * 16 + r] = o < GDB_CV ? fp32[PW_FH_B + o] : (o == GDB_CV ? fp32[PW_SIG_B] : 0.f);
+        }
+    p32.table(T32_AGG, PW_AGG_W, 1, lt(GDB_GF));
+    sec[S32_BAGG] = fp32[PW_AGG_B];
+    sec[S32_BW2] = fp32[PW_W2_B];
 }
 
 // ---- device side ----------------------------------------------------------------------------
@@ -185,8 +269,9 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // The 4 direction values are only ever an f16 MFMA operand: they are staged as two rows of packed halves (dir0|dir1,
 // dir2|dir3) - the same rounding, just earlier - which makes a view 33 rows: three views are 12,672 B, under the 12,800 B
 // at which twelve one-wave workgroups fit a CU (the LDS allocation granule is 1280 B: tools/ubench/simd_map.hip).
-constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND, STAGE_ROWS = NBLEND + 2;
-constexpr int STAGE_V = STAGE_ROWS * 32;     // 1056 floats = 4224 B
+// (The f32 path stages the 4 direction values as fp32 rows: 35 rows.)
+constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND;
+template <int PREC> constexpr int stage_v() { return (NBLEND + (PREC == GDB_PREC_F32 ? 4 : 2)) * 32; }  // floats per (wave, view): 4224 / 4480 B
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
 constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
@@ -195,19 +280,19 @@ constexpr int COMP_REC = COMP_WN + 32;                       // floats per slot 
 
 struct FusedArgs {
     DevFrame f;
-    const float* pw;  // packed weights (fp32 section, then MFMA section)
-    int row_begin, nrows, nseg, nsegs, ntiles, alias, skip;  // skip: timing-only ablation bits (GDB_FUSED_SKIP)
-    float* bf; float* depth; float* opac;
-    unsigned* dbg;
+    const float* pw;  // packed weights (fp32 section, then MFMA sections)
+    int row_begin, nrows, nseg, nsegs, ntiles, alias, skip;  // skip: timing-only ablation bits (diagnostic build)
+    int ldo;          // floats per output row of bf: NOUT, or NOUT + 2 for the packed layout [feat | depth | opacity]
+    float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
+    unsigned* dbg;    // diagnostic build only
 };
+// The product library keeps NO process-global mutable state: schedule and precision are arguments of
+// the entry point.  Only the diagnostic build (-DGDB_DIAG: tools/stamps.py, tools/valu_split.sh) has a debug buffer and
+// reads GDB_FUSED_SKIP from the environment.
+#ifdef GDB_DIAG
 static unsigned* g_dbg = nullptr;
 extern "C" void gdb_debug_set_buffer(void* p) { g_dbg = (unsigned*)p; }
-static int g_schedule = 0;  // GDB_SCHED_AUTO
-extern "C" int gdb_fused_set_schedule(int32_t mode) {
-    if (mode < 0 || mode > 2) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..2", mode);
-    g_schedule = mode;
-    return GDB_OK;
-}
+#endif
 
 // k-step S (0/1) of a 32x32 accumulator tile as the next layer's B operand (optionally through ReLU).
 template <int S, bool RELU>
@@ -501,13 +586,15 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 // Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns
 // false (and writes an empty composite record) when no lane has a sample in this slot.
 // Sample slot k of the bundle q (already loaded) for this lane: the views' contributions go to the wave's staging area.
+// vox[i] = voxel-feature channel 4h + i of this lane's sample.
+template <int PREC>
 __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, const float* __restrict__ tc, const Bundle<4>& q, int k, int bi,
-                                              int j, int h, int skip, bool act, float& z, half8& H1) {
+                                              int j, int h, int skip, bool act, float& z, float vox[4]) {
     const int V = f.V;
     float dn, ball, xyz[4][3], ctr[3];
     bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
-    float vox[4] = {0.f, 0.f, 0.f, 0.f};  // voxel feature, channels 4h..4h+3   :322-324
+    vox[0] = vox[1] = vox[2] = vox[3] = 0.f;  // voxel feature, channels 4h..4h+3   :322-324
     if (act && !SKIPPED(skip, 4)) {
         float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
         float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
@@ -546,11 +633,6 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
                 }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)vox[i];
-    H1[4] = (_Float16)1.f;  // constant one: carries the biases of lr0, weight.0, feat_head and sigma (weights there are zero for half 1)
     float xyzh[2][3];  // this half's two sub-ray points
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -558,7 +640,7 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
         for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
 
     for (int v = 0; v < V; ++v) {
-        float* st = stage + (size_t)v * STAGE_V;
+        float* st = stage + (size_t)v * stage_v<PREC>();
         // gather_view defines all 22 outputs; lanes without a sample in this slot stage unspecified values (never zeroed:
         // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
@@ -585,7 +667,10 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
             for (int e = 0; e < 4; ++e) st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
         st[(ROW_FEAT + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
         if (h == 0) st[(ROW_FEAT + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
-        if (h == 0) {
+        if (PREC == GDB_PREC_F32) {  // four fp32 rows; both halves computed the same code, each stores two of them
+            st[(ROW_DIR + 2 * h) * 32 + j] = h ? dir[2] : dir[0];
+            st[(ROW_DIR + 2 * h + 1) * 32 + j] = h ? dir[3] : dir[1];
+        } else if (h == 0) {
             typedef _Float16 half2v __attribute__((ext_vector_type(2)));
             const half2v p01 = {(_Float16)dir[0], (_Float16)dir[1]}, p23 = {(_Float16)dir[2], (_Float16)dir[3]};
             unsigned* su = (unsigned*)st;
@@ -597,8 +682,9 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
 
 // Workgroup-composite kernel: loads the bundle, decides whether the slot holds a sample; returns false (and writes an
 // empty composite record) when no lane has one.
+template <int PREC>
 __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, float* ck, const float* __restrict__ tc, const float* rng, int k,
-                                            int bi, int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, half8& H1) {
+                                            int bi, int row, int x, bool inrow, int j, int h, int skip, bool& act, float& z, float vox[4]) {
     Bundle<4> q;
     load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
     act = inrow && k < q.count;
@@ -607,7 +693,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
         if (h == 0) ck[COMP_ALPHA + j] = 0.f;
         return false;
     }
-    slot_gather_q(f, stage, tc, q, k, bi, j, h, skip, act, z, H1);
+    slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, skip, act, z, vox);
     return true;
 }
 
@@ -621,9 +707,16 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // without this each phase's first MFMA waits a full L2 round trip.
 // Outputs per lane (j, h): bacc[i] = blended channel 16h+i of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
 // channel 4h+i, sig = sigma pre-activation (valid in half 0).
-__device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const half8 H1, int lane, int j,
+__device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const float vox[4], int lane, int j,
                                               int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
     const int V = f.V;
+    constexpr int STAGE_V = stage_v<GDB_PREC_F16>();
+    half8 H1;  // k-step 1 of the [vox | im] operand: this half's 4 voxel channels, then the constant one
+#pragma unroll
+    for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)vox[i];
+    H1[4] = (_Float16)1.f;  // carries the biases of lr0, weight.0, feat_head and sigma (weights there are zero for half 1)
     f32x16 base;
     half8 a_view, a_ga0, a_ga1;
     f32x16 w_agg;
@@ -798,15 +891,216 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     STAMP(6);
 }
 
+// ---- the same MLP in fp32: v_mfma_f32_32x32x2_f32 (GDB_PREC_F32) -------------------------------------------------
+// Every layer is the reference's own fp32 arithmetic (nerf.py:84-115 never leaves fp32): the MFMA is bit for bit a
+// k-ordered fmaf chain with one rounding per product (MI355X_MICROARCH.md, FP32-input MFMA), the accumulator starts
+// from the layer's bias, and a finished accumulator register is the next layer's B operand as it stands (see the
+// section layout above) — no conversion, no LDS, no lane movement; ReLU is one integer max per register.
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 load_quad(const float* __restrict__ m32, int q, int lane) {
+    return ldu_pin<f32x4>(m32 + (size_t)q * 256, (unsigned)lane * 16u);
+}
+// acc += W[:, steps] · b over NS steps whose weight quads are already in registers
+template <int NS>
+__device__ __forceinline__ f32x16 chain32w(const f32x4* __restrict__ w, const float* __restrict__ b, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc = MFMA32(w[s >> 2][s & 3], b[s], acc);
+    }
+    return acc;
+}
+template <int NS>
+__device__ __forceinline__ void load_quads(const float* __restrict__ m32, int q0, int lane, f32x4* w) {
+#pragma unroll
+    for (int q = 0; q < (NS + 3) / 4; ++q) w[q] = load_quad(m32, q0 + q, lane);
+}
+template <int NS>
+__device__ __forceinline__ f32x16 chain32(const float* __restrict__ m32, int q0, int lane, const float* __restrict__ b, f32x16 acc) {
+    f32x4 w[(NS + 3) / 4];
+    load_quads<NS>(m32, q0, lane, w);
+    return chain32w<NS>(w, b, acc);
+}
+// This lane's B-operand registers of one staged view: the 19-vector feat ⊕ rgb in accumulator layout (register 4s+e
+// carries channel 8s + 4h + e; channels >= 19 are zeros) and the two direction steps (step s carries dir 2s + h).
+struct Tail32 { float fv[12]; float d[2]; };
+__device__ __forceinline__ Tail32 load_tail32(const float* __restrict__ st, int j, int h) {
+    Tail32 t;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int ch = 8 * s + 4 * h + e;
+            t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
+        }
+    t.d[0] = st[(ROW_DIR + h) * 32 + j];
+    t.d[1] = st[(ROW_DIR + 2 + h) * 32 + j];
+    return t;
+}
+// g_v = feat ⊕ rgb + ReLU(view_fc(dir)), registers 0..11 (accumulator layout)   nerf.py:69-71
+__device__ __forceinline__ void view_g32(const Tail32& t, const f32x4 q_view, const f32x16& b_view, float g[12]) {
+    f32x16 a = MFMA32(q_view[0], t.d[0], b_view);
+    a = MFMA32(q_view[1], t.d[1], a);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + relu1(a[i]);
+}
+
+// Same contract as slot_mlp_core.  `m32` = f32-MFMA section of the packed weights (global memory, L2-resident).
+__device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float* __restrict__ m32, const float* stage, const float vox[4], int lane,
+                                                  int j, int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
+    const int V = f.V;
+    constexpr int STAGE_V = stage_v<GDB_PREC_F32>();
+    f32x16 base;
+    f32x4 q_view;
+    {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+        q_view = load_quad(m32, Q_VIEW, lane_o);
+        const f32x16 b_view = load_tab(m32, T32_VIEW, h_o);
+        f32x4 wv[3], wm[3];
+        load_quads<12>(m32, Q_GVAR, lane_o, wv);
+        load_quads<12>(m32, Q_GMEAN, lane_o, wm);
+        base = load_tab(m32, T32_GLOB, h_o);
+        float mean[12], m2[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const Tail32 tl = load_tail32(stage + (size_t)v * STAGE_V, j, h);
+            float g[12];
+            view_g32(tl, q_view, b_view, g);
+            float inv = frcp((float)(v + 1));
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float d = g[i] - mean[i];
+                mean[i] = fmaf(d, inv, mean[i]);
+                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
+            }
+        }
+        float iv = frcp((float)(V - 1));
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m2[i] = m2[i] * iv;
+        // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
+        base = chain32w<12>(wv, m2, base);
+        base = chain32w<12>(wm, mean, base);
+    }
+    PHASE_FENCE();
+    STAMP(3);
+    float agg[16];
+    {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
+        const f32x16 b_view = load_tab(m32, T32_VIEW, h_o);
+        f32x4 wg[3];
+        load_quads<12>(m32, Q_GA, lane_o, wg);
+        const f32x16 w_agg = load_tab(m32, T32_AGG, h_o);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) agg[i] = 0.f;
+        float mx = -INFINITY, den = 0.f;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            float g[12];
+            view_g32(load_tail32(stage + (size_t)v * STAGE_V, j, h), q_view, b_view, g);
+            const f32x16 G = chain32w<12>(wg, g, base);
+            float sp = dot16_relu(G, w_agg);
+            float sv = relu1(sp + __shfl_xor(sp, 32) + b_agg);  // nerf.py:79
+            float mn = fmaxf(mx, sv);
+            float sc_old = __expf(mx - mn), e = __expf(sv - mn);
+            den = den * sc_old + e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) agg[i] = agg[i] * sc_old + e * relu1(G[i]);
+            mx = mn;
+        }
+        float r = frcp(den);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) agg[i] *= r;
+    }
+    PHASE_FENCE();
+    float hb[12];  // [vox | im] operand: steps 0..7 = ReLU(im) registers 0..7, steps 8..11 = vox
+    {   LANE_KEYS();  // im = ReLU(fc(agg))   nerf.py:82
+        const f32x16 im = chain32<16>(m32, Q_FC, lane_o, agg, load_tab(m32, T32_FC, h_o));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hb[i] = relu1(im[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hb[8 + i] = vox[i];
+    }
+    PHASE_FENCE();
+    STAMP(4);
+    float X[32];  // x = ReLU(lr0([vox | im])): [tile][register]   nerf.py:100-101
+    {   LANE_KEYS();
+        const f32x16 x0 = chain32<12>(m32, Q_LR0, lane_o, hb, load_tab(m32, T32_LR0, h_o));
+        const f32x16 x1 = chain32<12>(m32, Q_LR0 + 3, lane_o, hb, load_tab(m32, T32_LR0 + 32, h_o));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { X[i] = relu1(x0[i]); X[16 + i] = relu1(x1[i]); }
+    }
+    PHASE_FENCE();
+    {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
+        const f32x16 fh = chain32<32>(m32, Q_FH, lane_o, X, load_tab(m32, T32_FH, h_o));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fhv[i] = relu1(fh[i]);
+        sig = fh[4];
+    }
+    PHASE_FENCE();
+    // shared part of weight.0: bias + columns on x and on [vox | im]   nerf.py:106-109
+    f32x16 hs0, hs1;
+    {   LANE_KEYS();
+        hs0 = chain32<32>(m32, Q_W0A, lane_o, X, load_tab(m32, T32_W0, h_o));
+        hs0 = chain32<12>(m32, Q_W0B, lane_o, hb, hs0);
+    }
+    PHASE_FENCE();
+    {   LANE_KEYS();
+        hs1 = chain32<32>(m32, Q_W0A + 8, lane_o, X, load_tab(m32, T32_W0 + 32, h_o));
+        hs1 = chain32<12>(m32, Q_W0B + 3, lane_o, hb, hs1);
+    }
+    PHASE_FENCE();
+    STAMP(5);
+    // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+    {
+        LANE_KEYS();
+        f32x4 wc0[4], wc1[4];  // loop-invariant: loaded once per slot
+        load_quads<14>(m32, Q_W0C, lane_o, wc0);
+        load_quads<14>(m32, Q_W0C + 4, lane_o, wc1);
+        const f32x16 w20 = load_tab(m32, T32_W2, h_o), w21 = load_tab(m32, T32_W2 + 32, h_o);
+        float mx = -INFINITY, den = 0.f;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const float* st = stage + (size_t)v * STAGE_V;
+            const Tail32 t = load_tail32(st, j, h);
+            float tb[14];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) tb[i] = t.fv[i];
+            tb[12] = t.d[0]; tb[13] = t.d[1];
+            float up = dot16_relu(chain32w<14>(wc0, tb, hs0), w20);
+            up += dot16_relu(chain32w<14>(wc1, tb, hs1), w21);
+            float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
+            float mn = fmaxf(mx, uv);
+            float sc_old = __expf(mx - mn), e = __expf(uv - mn);
+            den = den * sc_old + e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int c = 16 * h + i;
+                float val = c < NBLEND ? st[c * 32 + j] : 0.f;
+                bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
+            }
+            mx = mn;
+        }
+        float r = frcp(den);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] *= r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    STAMP(6);
+}
+
 // alpha = 1 - exp(-softplus(sig)) (nerf.py:102 Softplus, utils.py:34) = 1 - 1/(1 + e^sig) = sigmoid(sig): one exp and one
 // reciprocal instead of log1p(exp()) followed by another exp (beyond Softplus's threshold 20 the two differ by e^-40)
 __device__ __forceinline__ float alpha_of(float sig) { return frcp(1.f + __expf(-sig)); }
 
 // Workgroup-composite kernel: MLP of one slot, then the slot's composite record.
+template <int PREC>
 __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restrict__ mf, const float* stage, float* ck, bool act, float z,
-                                         const half8 H1, int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
+                                         const float vox[4], int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
     float bacc[16], fhv[4], sig;
-    slot_mlp_core(f, mf, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+    if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+    else slot_mlp_core(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -825,12 +1119,14 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
 // Composite of one segment from its S slot records in LDS (all threads of the team; two workgroup barriers inside):
 // transmittance weights per bundle, normalised (utils.py:35-41), then the weighted sums (utils.py:109-119) written as
 // the segment's contiguous (32 x 39) block, depth and opacity (network.py:88-89).  SC > 0: S == SC at compile time.
-template <int SC>
+// PACKED: output rows are [feat 39 | depth | opacity] (41 floats, one contiguous run per segment; the multi-GPU gather unit).
+template <int SC, bool PACKED>
 __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, size_t rec_stride, int S_rt, int tt, int tthreads,
                                           int seg, int row, int bi) {
     const DevFrame& f = a.f;
     const int S = SC > 0 ? SC : S_rt;
     constexpr int NK = SC > 0 ? SC : 1;
+    constexpr int LDO = PACKED ? NOUT + 2 : NOUT;
     if (tt < 32) {
         if (SC > 0) {
             float al[NK], w[NK], T = 1.f, sum = 0.f;
@@ -861,32 +1157,35 @@ __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, s
     __syncthreads();
     const int nvalid = min(32, f.W - seg * 32);
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
-    for (int qi = tt; qi < nvalid * NOUT; qi += tthreads) {
-        int jj = qi / NOUT, c = qi - jj * NOUT;
+    // sum over the slots of weight x record row cr of bundle jj (is_op: of the weight alone = opacity); one code path for both
+    // output layouts, so that they agree bit for bit
+    auto chan_sum = [&](int cr, int jj, bool is_op) {
         float acc = 0.f;
         if (SC > 0) {
             float v[NK], w[NK];
 #pragma unroll
-            for (int k = 0; k < NK; ++k) { const float* rk = rec_team + (size_t)k * rec_stride; v[k] = rk[c * COMP_LD + jj]; w[k] = rk[COMP_WN + jj]; }
+            for (int k = 0; k < NK; ++k) { const float* rk = rec_team + (size_t)k * rec_stride; v[k] = rk[cr * COMP_LD + jj]; w[k] = rk[COMP_WN + jj]; }
 #pragma unroll
-            for (int k = 0; k < NK; ++k) acc += v[k] * w[k];
+            for (int k = 0; k < NK; ++k) acc = fmaf(is_op ? 1.f : v[k], w[k], acc);
         } else {
             for (int k = 0; k < S; ++k) {
                 const float* rk = rec_team + (size_t)k * rec_stride;
-                acc += rk[c * COMP_LD + jj] * rk[COMP_WN + jj];
+                acc = fmaf(is_op ? 1.f : rk[cr * COMP_LD + jj], rk[COMP_WN + jj], acc);
             }
         }
-        a.bf[b0 * NOUT + qi] = acc;
+        return acc;
+    };
+    for (int qi = tt; qi < nvalid * LDO; qi += tthreads) {
+        int jj = qi / LDO, c = qi - jj * LDO;
+        const bool is_op = PACKED && c == NOUT + 1;  // opacity = sum of the weights; row NOUT of a record is z
+        float acc = chan_sum(is_op ? 0 : c, jj, is_op);
+        if (PACKED && c == NOUT && f.inv_depth) acc = 1.f / acc;  // network.py:88-89
+        a.bf[b0 * LDO + qi] = acc;
     }
-    if (tt < 64) {
+    if (!PACKED && tt < 64) {
         int jj = tt & 31, which = tt >> 5;
         if (jj < nvalid) {
-            float acc = 0.f;
-            for (int k = 0; k < S; ++k) {
-                const float* rk = rec_team + (size_t)k * rec_stride;
-                float w = rk[COMP_WN + jj];
-                acc += which ? w : rk[NOUT * COMP_LD + jj] * w;
-            }
+            const float acc = chan_sum(which ? 0 : NOUT, jj, which != 0);
             if (which) a.opac[b0 + jj] = acc;
             else a.depth[b0 + jj] = f.inv_depth ? 1.f / acc : acc;  // network.py:88-89
         }
@@ -896,8 +1195,9 @@ __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, s
 // Workgroup = one 32-bundle segment x S sample slots, one wave per slot; LOOP: fewer waves than slots, the waves loop
 // over slots.  The MLP weights come from global memory (L2-resident): an LDS-resident copy shared by a 9-12 wave
 // workgroup was measured 25-30 % slower (it caps the CU at 6-9 waves), see DESIGN.md.
-template <bool LOOP, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
+// PREC: GDB_PREC_F16 (f16 MFMA operands, 3 waves per SIMD) or GDB_PREC_F32 (fp32 MFMA, matrix-pipe-bound: 2 waves per SIMD).
+template <bool LOOP, int WAVES, int PREC>
+__global__ void __launch_bounds__(64 * WAVES, (PREC == GDB_PREC_F32 || LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     // the wave index is uniform but derived from threadIdx: without readfirstlane everything computed from it (team,
@@ -918,9 +1218,9 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
     const int x = seg * 32 + j;
     const bool inrow = x < f.W;
 
-    // LDS: [per-wave staging V x STAGE_V] [composite records unless aliased].  With one slot per wave the record of
+    // LDS: [per-wave staging V x stage_v] [composite records unless aliased].  With one slot per wave the record of
     // slot k reuses wave k's own staging area, dead by then.
-    const size_t wave_fl = (size_t)V * STAGE_V;
+    const size_t wave_fl = (size_t)V * stage_v<PREC>();
     float* stage = smem + (size_t)wid * wave_fl;
     const bool alias = a.alias != 0;
     const size_t rec_stride = alias ? wave_fl : (size_t)COMP_REC;
@@ -933,28 +1233,29 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
 #pragma unroll
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
-    const float* mfg = a.pw + PW_FP32_FLOATS;
-    const float b_agg = kptr(mfg)[TS_BAGG], b_w2 = kptr(mfg)[TS_BW2];  // the two scalar biases (agg_w_fc, weight.2)
+    // MFMA section of the packed weights for this precision, and the two scalar biases (agg_w_fc, weight.2)
+    const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
+    const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
 
     STAMP(0);
     if (LOOP) {
         for (int k = k0; k < S; k += nw) {
             float* ck = rec_team + (size_t)k * rec_stride;
-            bool act; float z; half8 H1;
-            if (slot_gather(f, stage, ck, tc, rng, k, bi, row, x, inrow, j, h, a.skip, act, z, H1)) {
+            bool act; float z; float vox[4];
+            if (slot_gather<PREC>(f, stage, ck, tc, rng, k, bi, row, x, inrow, j, h, a.skip, act, z, vox)) {
                 __builtin_amdgcn_wave_barrier();
                 PHASE_FENCE();
-                if (!SKIPPED(a.skip, 8)) slot_mlp(f, mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+                if (!SKIPPED(a.skip, 8)) slot_mlp<PREC>(f, mfg, stage, ck, act, z, vox, lane, j, h, b_agg, b_w2, dbg);
             }
         }
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
         float* ck = rec_team + (size_t)k0 * rec_stride;
-        bool act; float z; half8 H1;
-        const bool any = slot_gather(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, H1);
+        bool act; float z; float vox[4];
+        const bool any = slot_gather<PREC>(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, vox);
         STAMP(2);
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
-        if (any && !SKIPPED(a.skip, 8)) slot_mlp(f, mfg, stage, ck, act, z, H1, lane, j, h, b_agg, b_w2, dbg);
+        if (any && !SKIPPED(a.skip, 8)) slot_mlp<PREC>(f, mfg, stage, ck, act, z, vox, lane, j, h, b_agg, b_w2, dbg);
     }
     STAMP(7);
     __syncthreads();
@@ -962,12 +1263,19 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
     const int tt = threadIdx.x, tthreads = (int)blockDim.x;
     // The slot count is tiny: with it as a compile-time constant the S reads of a sum are all in flight before the first
     // is used (as a runtime loop every iteration waited for its own LDS read).
-    switch (S) {
-        case 1: composite<1>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
-        case 2: composite<2>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
-        case 3: composite<3>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
-        case 4: composite<4>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
-        default: composite<0>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+    if (a.ldo == NOUT) {
+        switch (S) {
+            case 1: composite<1, false>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+            case 2: composite<2, false>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+            case 3: composite<3, false>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+            case 4: composite<4, false>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+            default: composite<0, false>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        }
+    } else {
+        switch (S) {
+            case 3: composite<3, true>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+            default: composite<0, true>(a, rec_team, rec_stride, S, tt, tthreads, seg, row, bi); break;
+        }
     }
     STAMP(9);
 }
@@ -978,8 +1286,9 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
 // slot and the composite pass, and a frame's waves fit on the chip in fewer rounds (c2: 2560 waves, one round).
 // Lane (j, h) owns blended channels 16h..16h+15 and feat_head channels 4h..4h+3 of bundle j; transmittance, weight
 // sum and depth are kept by both halves.  utils.py:35-41 (weights), :109-119 (sums), network.py:83-89 (depth).
-__global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
-    float* stage = (float*)smem4;  // V x STAGE_V floats; reused for the output transpose at the end
+template <int PREC>
+__global__ void __launch_bounds__(64, PREC == GDB_PREC_F32 ? 2 : 3) k_render_solo(FusedArgs a_) {
+    float* stage = (float*)smem4;  // V x stage_v floats; reused for the output transpose at the end
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     // Everything wave-uniform (kernel arguments, camera block, pointers) is re-derived inside each slot iteration from
     // an opaque pointer to the kernel arguments: as loop invariants they would be live across the whole loop body and
@@ -1031,18 +1340,19 @@ __global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
 #pragma unroll
             for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
         }
-        const float* mfg = a.pw + PW_FP32_FLOATS;
-        const float b_agg = kptr(mfg)[TS_BAGG], b_w2 = kptr(mfg)[TS_BW2];
-        float z; half8 H1;
+        const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
+        const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
+        float z; float vox[4];
         {
             Bundle<4> q;  // recomputed per slot from the pre-loaded ranges: cheaper than ~24 registers live across the loop
             load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
-            slot_gather_q(f, stage, tc, q, k, bi, j, h, a.skip, act, z, H1);
+            slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
         }
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
         float bacc[16], fhv[4], sig;
-        slot_mlp_core(f, mfg, stage, H1, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        else slot_mlp_core(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
         const float sig0 = __shfl(sig, j);  // sigma sits in half 0
         if (act) {  // lanes without a sample hold unspecified MLP outputs: keep them out of the sums
             const float al = alpha_of(sig0);
@@ -1062,7 +1372,7 @@ __global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
     const DevFrame& f = a.f;
     const float rden = 1.f / fmaxf(wsum, 1e-6f);
     __builtin_amdgcn_wave_barrier();
-    float* o = stage;  // [NOUT + 2][COMP_LD]
+    float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int c = 16 * h + i;
@@ -1070,52 +1380,112 @@ __global__ void __launch_bounds__(64, 3) k_render_solo(FusedArgs a_) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + j] = of[i] * rden;
-    if (h == 0) { o[NOUT * COMP_LD + j] = dz * rden; o[(NOUT + 1) * COMP_LD + j] = wsum * rden; }
+    if (h == 0) {
+        const float d = dz * rden;
+        o[NOUT * COMP_LD + j] = f.inv_depth ? 1.f / d : d;  // network.py:88-89
+        o[(NOUT + 1) * COMP_LD + j] = wsum * rden;
+    }
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     const int nvalid = min(32, f.W - seg * 32);
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
-    for (int qi = lane; qi < nvalid * NOUT; qi += 64) {
-        int jj = qi / NOUT, c = qi - jj * NOUT;
-        a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
-    }
-    if (j < nvalid) {
-        if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
-        else { float d = o[NOUT * COMP_LD + j]; a.depth[b0 + j] = f.inv_depth ? 1.f / d : d; }
+    if (a.ldo == NOUT) {
+        for (int qi = lane; qi < nvalid * NOUT; qi += 64) {
+            int jj = qi / NOUT, c = qi - jj * NOUT;
+            a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
+        }
+        if (j < nvalid) {
+            if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
+            else a.depth[b0 + j] = o[NOUT * COMP_LD + j];
+        }
+    } else {  // packed rows [feat | depth | opacity]
+        constexpr int LDO = NOUT + 2;
+        for (int qi = lane; qi < nvalid * LDO; qi += 64) {
+            int jj = qi / LDO, c = qi - jj * LDO;
+            a.bf[b0 * LDO + qi] = o[c * COMP_LD + jj];
+        }
     }
 }
 
+// LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
+// function: the once-flag is a bit per device ordinal (relaxed atomics; setting it twice is harmless).
+#include <atomic>
+template <class K>
+static hipError_t allow_big_lds(K kernel, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev < 64) done.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}
+
+template <int PREC>
 static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_solo, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    hipLaunchKernelGGL(k_render_solo, dim3(grid), dim3(64), lds, st, a);
+    static std::atomic<unsigned long long> done{0};
+    hipError_t e = allow_big_lds(k_render_solo<PREC>, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_render_solo<PREC>, dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
-template <bool LOOP, int WAVES>
+template <bool LOOP, int WAVES, int PREC>
 static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_fused<LOOP, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_render_fused<LOOP, WAVES>), dim3(grid), dim3(64 * nw), lds, st, a);
+    static std::atomic<unsigned long long> done{0};
+    hipError_t e = allow_big_lds(k_render_fused<LOOP, WAVES, PREC>, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_render_fused<LOOP, WAVES, PREC>), dim3(grid), dim3(64 * nw), lds, st, a);
     return hipGetLastError();
 }
 
-extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
-                                        int32_t row_begin, int32_t row_end, int32_t precision, float* bf, float* depth,
-                                        float* opac, void* stream_) {
+template <int PREC>
+static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, int sched, hipStream_t st) {
+    const int S = cfg->max_num_samples, V = fr->V;
+    const size_t per_wave = sizeof(float) * (size_t)V * stage_v<PREC>();
+    const size_t lds_max = 160 * 1024;
+    const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
+    hipError_t e;
+    // Two schedules (measured on MI355X, profiles/r01/schedules.txt):
+    //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
+    //                  most slots hold a sample: S_max = 3 (c2, 80 % of the lanes active: 62 vs 72 us; c3 105 vs 126 us).
+    //  * segment wave - one wave walks all slots of its segment, composite in registers.  Best when slots are sparsely
+    //                  filled or the S-wave workgroup is LDS-limited: c4 (S_max 6 adaptive) 171 vs 296 us, c5 1346 vs 1490 us.
+    const bool want_solo = sched == GDB_SCHED_SEGMENT_WAVE || (sched == GDB_SCHED_AUTO && S > 3);
+    const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
+    a.ntiles = a.nsegs;
+    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
+        a.alias = 0;
+        e = launch_solo<PREC>(a, grid, solo_lds, st);
+    } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot
+        a.alias = 1;
+        if (S <= 4) e = launch_fused<false, 4, PREC>(a, grid, S, (size_t)S * per_wave, st);
+        else e = launch_fused<false, 8, PREC>(a, grid, S, (size_t)S * per_wave, st);
+    } else {  // more slots than waves fit: waves loop over slots, separate composite records
+        const size_t fixed = sizeof(float) * (size_t)S * COMP_REC;
+        int nw = S < 4 ? S : 4;
+        nw = (S + (S + nw - 1) / nw - 1) / ((S + nw - 1) / nw);
+        while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
+        const size_t lds = fixed + nw * per_wave;
+        if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
+        a.alias = 0;
+        e = launch_fused<true, 4, PREC>(a, grid, nw, lds, st);
+    }
+    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
+    return GDB_OK;
+}
+
+static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw, int32_t row_begin, int32_t row_end,
+                        int32_t precision, int32_t schedule, float* bf, float* depth, float* opac, int ldo, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, fr, true); if (rc) return rc;
-    if (!ws || !pw || !bf || !depth || !opac) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (!ws || !pw || !bf || (ldo == NOUT && (!depth || !opac))) return gdb_fail(GDB_E_BADARG, "NULL pointer");
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
-    if (precision != 0) return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA, f32 accumulate)", precision);
+    if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32)
+        return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA)", precision);
+    if (schedule < 0 || schedule > 2) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..2", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
     if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
@@ -1134,44 +1504,24 @@ extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr
     a.row_begin = row_begin; a.nrows = row_end - row_begin;
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
-    a.bf = bf; a.depth = depth; a.opac = opac; a.dbg = g_dbg;
-    // experiment switches, read once: GDB_FUSED_SKIP (timing-only ablation bits, diagnostic build), GDB_FUSED_SOLO
+    a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
+    a.dbg = nullptr; a.skip = 0;
+#ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
-    a.skip = env_skip;
-    const int S = cfg->max_num_samples, V = fr->V;
-    const size_t per_wave = sizeof(float) * (size_t)V * STAGE_V;
-    const size_t lds_max = 160 * 1024;
-    const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
+    a.skip = env_skip; a.dbg = g_dbg;
+#endif
     hipStream_t st = (hipStream_t)stream_;
-    hipError_t e;
-    // Two schedules (gdb_fused_set_schedule; measured on MI355X, profiles/r01/schedules.txt):
-    //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
-    //                  most slots hold a sample: S_max = 3 (c2, 80 % of the lanes active: 62 vs 72 us; c3 105 vs 126 us).
-    //  * segment wave - one wave walks all slots of its segment, composite in registers.  Best when slots are sparsely
-    //                  filled or the S-wave workgroup is LDS-limited: c4 (S_max 6 adaptive) 171 vs 296 us, c5 1346 vs 1490 us.
-    static const char* env_sched = getenv("GDB_FUSED_SOLO");  // experiment override: "0" slot waves, "1" segment wave
-    const int sched = env_sched ? (env_sched[0] == '0' ? 1 : 2) : g_schedule;
-    const bool want_solo = sched == 2 || (sched == 0 && S > 3);
-    const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
-    a.ntiles = a.nsegs;
-    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-    if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
-        a.alias = 0;
-        e = launch_solo(a, grid, solo_lds, st);
-    } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot
-        a.alias = 1;
-        if (S <= 4) e = launch_fused<false, 4>(a, grid, S, (size_t)S * per_wave, st);
-        else e = launch_fused<false, 8>(a, grid, S, (size_t)S * per_wave, st);
-    } else {  // more slots than waves fit: waves loop over slots, separate composite records
-        const size_t fixed = sizeof(float) * (size_t)S * COMP_REC;
-        int nw = S < 4 ? S : 4;
-        nw = (S + (S + nw - 1) / nw - 1) / ((S + nw - 1) / nw);
-        while (nw > 1 && fixed + nw * per_wave > lds_max) --nw;
-        const size_t lds = fixed + nw * per_wave;
-        if (lds > lds_max) return gdb_fail(GDB_E_SHAPE, "V=%d, S_max=%d needs %zu B of LDS (> %zu)", V, S, lds, lds_max);
-        a.alias = 0;
-        e = launch_fused<true, 4>(a, grid, nw, lds, st);
-    }
-    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
-    return GDB_OK;
+    return precision == GDB_PREC_F32 ? render_launch<GDB_PREC_F32>(a, cfg, fr, schedule, st) : render_launch<GDB_PREC_F16>(a, cfg, fr, schedule, st);
+}
+
+extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
+                                        int32_t row_begin, int32_t row_end, int32_t precision, int32_t schedule, float* bf,
+                                        float* depth, float* opac, void* stream_) {
+    return render_entry(cfg, fr, ws, pw, row_begin, row_end, precision, schedule, bf, depth, opac, NOUT, stream_);
+}
+
+extern "C" int gdb_render_bundles_packed(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,
+                                         int32_t row_begin, int32_t row_end, int32_t precision, int32_t schedule, float* out,
+                                         void* stream_) {
+    return render_entry(cfg, fr, ws, pw, row_begin, row_end, precision, schedule, out, nullptr, nullptr, NOUT + 2, stream_);
 }

@@ -34,6 +34,18 @@ _FRAME_SHAPES = {
 }
 
 
+def _on_device(method):
+    """Run an engine method with the engine's device current: the C ABI launches on a stream of that device, and HIP
+    launches go to the CURRENT device (a second engine on another GPU of the same process must not inherit it)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -69,6 +81,8 @@ class HotPathEngine:
         self._frame: Optional[GdbFrame] = None
         self._keep: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
+        self.schedule = _lib.SCHED_AUTO
+        self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
 
     # ---- derived sizes -------------------------------------------------------------------
     @property
@@ -113,6 +127,7 @@ class HotPathEngine:
         self.weights = torch.from_numpy(host).to(self.device)
 
     # ---- per-frame preparation -----------------------------------------------------------
+    @_on_device
     def prepare(self, frame: Dict[str, torch.Tensor], im_size=None) -> None:
         """Validate shapes on the host, then build the camera block and the feature pyramid.  A frame
         without the source side (only tar_ext, tar_int, near_far [, depth_range, vol_range]; pass
@@ -156,6 +171,7 @@ class HotPathEngine:
             _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
 
     # ---- next row N1: merge around the decoder ------------------------------------------------
+    @_on_device
     def merge(self, bundle_feat, rgb_c=None, bundle_depth=None, bundle_opacity=None, reweighting: bool = False):
         """network.py:170-182 on the frame last prepared: img = rgb_c + pixel_shuffle(bundle_feat[:, :3 b^2], b) (re-weighted
         if asked), bundle depth / opacity maps upsampled x b.  Returns (img (B,3,Ho,Wo), depth (B,Ho,Wo) | None, opacity | None)."""
@@ -179,9 +195,11 @@ class HotPathEngine:
         return img, outs[0], outs[1]
 
     def set_schedule(self, mode: int) -> None:
-        """Work decomposition of the fused kernel (process-wide): 0 auto, 1 one wave per sample slot, 2 one wave per
-        32-bundle segment.  See include/gdb_nerf_hip.h."""
-        _lib.check(self.lib.gdb_fused_set_schedule(int(mode)))
+        """Work decomposition of THIS engine's fused calls (a per-call argument of the C ABI, no process-wide state):
+        0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment.  See include/gdb_nerf_hip.h."""
+        if int(mode) not in (0, 1, 2):
+            raise ValueError(f"schedule {mode} outside 0..2")
+        self.schedule = int(mode)
 
     def feature_pyramid(self):
         """The mip pyramid `prepare` built, as nvdiffrast would hold it: a list over levels of
@@ -211,6 +229,7 @@ class HotPathEngine:
         return f.B * f.H * f.W
 
     # ---- operator mirrors ----------------------------------------------------------------
+    @_on_device
     def build_rays(self) -> Dict[str, torch.Tensor]:
         f = self._need_frame()
         dev = self.device
@@ -221,6 +240,7 @@ class HotPathEngine:
             "rays_d", "uv", "rays_o", "z_axis", "tar_pixel_radius")), self._stream()))
         return out
 
+    @_on_device
     def sample(self) -> Dict[str, torch.Tensor]:
         """Arrays are allocated for N_max = n_bundles * S_max; `total` (device int64) holds the valid count."""
         f = self._need_frame()
@@ -237,6 +257,7 @@ class HotPathEngine:
             self._stream()))
         return out
 
+    @_on_device
     def encode(self, rays_xyz: torch.Tensor, uvd: torch.Tensor, ball_radii: torch.Tensor,
                samples_per_batch: torch.Tensor, total: torch.Tensor):
         f = self._need_frame()
@@ -251,6 +272,7 @@ class HotPathEngine:
                                        rfd.data_ptr(), vox.data_ptr(), self._stream()))
         return rfd, vox
 
+    @_on_device
     def mlp(self, vox_feat: torch.Tensor, rgbs_feat_dir: torch.Tensor, total: Optional[torch.Tensor] = None):
         if self.weights is None:
             raise ValueError("load_weights() first")
@@ -264,6 +286,7 @@ class HotPathEngine:
                                     _ptr(total), n, sigma.data_ptr(), feat.data_ptr(), self._stream()))
         return sigma, feat
 
+    @_on_device
     def composite(self, sigma: torch.Tensor, feat: torch.Tensor, z_vals: torch.Tensor, indices: torch.Tensor,
                   n_bundles: int, total: Optional[torch.Tensor] = None):
         n, ch = feat.shape
@@ -282,6 +305,7 @@ class HotPathEngine:
                                           depth.data_ptr(), opac.data_ptr(), scratch.data_ptr(), self._stream()))
         return weights, bf, depth, opac
 
+    @_on_device
     def render_weights(self, sigma: torch.Tensor, indices: torch.Tensor, n_bundles: int, total: Optional[torch.Tensor] = None):
         n = sigma.shape[0]
         _chk(sigma, "sigma", (n,)); _chk(indices, "indices", (n,), torch.int64)
@@ -291,6 +315,7 @@ class HotPathEngine:
                                                weights.data_ptr(), scratch.data_ptr(), self._stream()))
         return weights
 
+    @_on_device
     def accumulate(self, weights: torch.Tensor, feat: torch.Tensor, z_vals: torch.Tensor, indices: torch.Tensor, n_bundles: int,
                    total: Optional[torch.Tensor] = None):
         n, ch = feat.shape
@@ -312,12 +337,15 @@ class HotPathEngine:
         return bf, depth, opac
 
     # ---- production entry ----------------------------------------------------------------
-    def render(self, row_begin: int = 0, row_end: Optional[int] = None, precision: int = 0, out=None):
-        """Fused hot path over bundle-map rows [row_begin,row_end) of every batch item."""
+    @_on_device
+    def render(self, row_begin: int = 0, row_end: Optional[int] = None, precision: Optional[int] = None, out=None):
+        """Fused hot path over bundle-map rows [row_begin,row_end) of every batch item.  precision: None = this engine's
+        default (`self.precision`), 0 = f16 MFMA operands, 1 = fp32 MFMA (the reference's precision)."""
         if self.weights is None:
             raise ValueError("load_weights() first")
         f = self._need_frame()
         row_end = f.H if row_end is None else row_end
+        precision = self.precision if precision is None else precision
         nb = self.n_bundles
         if out is None:
             out = (torch.zeros((nb, self.Q), device=self.device), torch.zeros((nb,), device=self.device),
@@ -325,6 +353,25 @@ class HotPathEngine:
         bf, depth, opac = out
         _chk(bf, "bundle_feat", (nb, self.Q)); _chk(depth, "depth", (nb,)); _chk(opac, "opacity", (nb,))
         _lib.check(self.lib.gdb_render_bundles_fused(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
-                                                     int(row_begin), int(row_end), int(precision), bf.data_ptr(), depth.data_ptr(),
-                                                     opac.data_ptr(), self._stream()))
+                                                     int(row_begin), int(row_end), int(precision), int(self.schedule), bf.data_ptr(),
+                                                     depth.data_ptr(), opac.data_ptr(), self._stream()))
         return bf, depth, opac
+
+    @_on_device
+    def render_packed(self, row_begin: int = 0, row_end: Optional[int] = None, precision: Optional[int] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same into ONE (n_bundles, Q + 2) tensor, row = [bundle_feat | depth | opacity]: a row strip is one contiguous
+        block, which makes the multi-GPU exchange a single all-gather (parallel.gather_packed)."""
+        if self.weights is None:
+            raise ValueError("load_weights() first")
+        f = self._need_frame()
+        row_end = f.H if row_end is None else row_end
+        precision = self.precision if precision is None else precision
+        nb = self.n_bundles
+        if out is None:
+            out = torch.zeros((nb, self.Q + 2), device=self.device)
+        _chk(out, "out", (nb, self.Q + 2))
+        _lib.check(self.lib.gdb_render_bundles_packed(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
+                                                      int(row_begin), int(row_end), int(precision), int(self.schedule),
+                                                      out.data_ptr(), self._stream()))
+        return out

@@ -17,8 +17,10 @@
  *  - Return value: GDB_OK (0) or a negative GdbStatus; gdb_last_error() returns a
  *    thread-local message for the last failure on the calling thread.  Shape / config
  *    violations are rejected before any launch.  The operator mirrors are NaN-transparent
- *    like the reference; the fused kernel converts activations to f16 with a clamp to the
- *    finite f16 range, which does not preserve NaN.
+ *    like the reference; the fused kernel at GDB_PREC_F16 converts activations to f16
+ *    (|x| > 65504 becomes inf); at GDB_PREC_F32 it computes the MLP in fp32 throughout.
+ *  - No process-global mutable state: every function is reentrant; the only per-thread state
+ *    is the gdb_last_error() message.
  */
 #ifndef GDB_NERF_HIP_H
 #define GDB_NERF_HIP_H
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 1
+#define GDB_ABI_VERSION 2
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -183,20 +185,34 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  * encode → render_bundles) in one pass with no intermediate in HBM.  Needs gdb_prepare on
  * the same workspace first.  row_begin/row_end select a strip of bundle-map rows
  * [row_begin,row_end) of every batch item (multi-GPU row-strip sharding); outputs are full
- * size and only the strip's rows are written.  precision: 0 = fp16 MFMA, fp32 accumulate.
+ * size and only the strip's rows are written.
+ *
+ * precision (arithmetic of the NeRF MLP, nerf.py:84-115; fetch, geometry and composite are fp32 either way):
+ *   GDB_PREC_F16  f16 MFMA operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) — narrower than the reference;
+ *   GDB_PREC_F32  fp32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain, one rounding per product) —
+ *                 the reference's own precision.
+ * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
+ *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
+ *   its 32 bundles with the composite in registers.
+ * Both are per-call arguments: the library keeps no process-global state (two engines with different settings may
+ * interleave calls on different streams or threads).
  * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
-int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
-                             const float* d_packed_weights, int32_t row_begin, int32_t row_end,
-                             int32_t precision, float* d_bundle_feat, float* d_depth, float* d_opacity,
-                             void* stream);
-
-/* Work decomposition of gdb_render_bundles_fused (process-wide tuning knob; results agree to rounding):
- * 0 GDB_SCHED_AUTO (default: by shape), 1 GDB_SCHED_SLOT_WAVES (one wave per sample slot, composite through
- * LDS), 2 GDB_SCHED_SEGMENT_WAVE (one wave walks all slots of its 32 bundles, composite in registers). */
+#define GDB_PREC_F16 0
+#define GDB_PREC_F32 1
 #define GDB_SCHED_AUTO 0
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2
-int gdb_fused_set_schedule(int32_t mode);
+int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
+                             const float* d_packed_weights, int32_t row_begin, int32_t row_end,
+                             int32_t precision, int32_t schedule, float* d_bundle_feat, float* d_depth,
+                             float* d_opacity, void* stream);
+
+/* The same with ONE output buffer d_out (B*H*W, Q+2), row = [bundle_feat (Q) | depth | opacity]: what
+ * Network.render_bundles returns (network.py:54-91) as a single tensor, so that a row strip is one contiguous
+ * block and the multi-GPU exchange is a single all-gather. */
+int gdb_render_bundles_packed(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
+                              const float* d_packed_weights, int32_t row_begin, int32_t row_end,
+                              int32_t precision, int32_t schedule, float* d_out, void* stream);
 
 /* ---- "next" rows: the step just before the hot path ------------------------ */
 /* build_feature_volume, networks/gdb_nerf/depth_net.py:424-476: plane-sweep warp of the source feature maps

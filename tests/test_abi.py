@@ -125,14 +125,17 @@ int main(void) {
     GdbConfig c; GdbFrame f;
     if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
     for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
-    if (gdb_abi_version() != 1) return 12;
+    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 2) return 12;
     memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
     c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
     if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */
     if (!strstr(gdb_last_error(), "power of 2")) return 14;
     c.bundle_size = 2;
     if (gdb_packed_weight_floats(&c, &n) != GDB_OK || n < 11930) return 15;
-    if (gdb_fused_set_schedule(7) != GDB_E_BADARG || gdb_fused_set_schedule(GDB_SCHED_AUTO) != GDB_OK) return 16;
+    /* argument checking happens on the host, before any launch: an unknown precision / schedule is refused */
+    c.is_adaptive = 1; c.max_mipmap_level = 3; c.viewdir_agg = 1;
+    f.B = 1; f.V = 3; f.Ho = 64; f.Wo = 80; f.H = 32; f.W = 40; f.D = 8;
+    if (gdb_render_bundles_packed(&c, &f, NULL, NULL, 0, 32, GDB_PREC_F32, GDB_SCHED_AUTO, NULL, NULL) != GDB_E_BADARG) return 16;
     printf("%%zu entry points, %%zu packed floats\\n", sizeof fns / sizeof fns[0], n);
     return 0;
 }

@@ -60,3 +60,50 @@ def test_gather_strips_gloo(world, B, H, W, C):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+class _FakeEngine:
+    """Stands in for HotPathEngine.render_packed on the CPU: writes the rows it is asked for, and only those."""
+
+    def __init__(self, truth):
+        self.truth = truth
+
+    def render_packed(self, r0, r1, precision, out):
+        H = self.truth.shape[0]
+        out.view(H, -1)[r0:r1] = self.truth[r0:r1]
+        return out
+
+
+def _packed_worker(rank, world, port, H, W, C, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdb_nerf_amd.parallel import StripGather
+        truth = torch.arange(H * W * C, dtype=torch.float32).view(H, W * C)
+        g = StripGather(H, W, C, world, rank, "cpu", dist)
+        g.full.fill_(float("nan"))
+        ok = True
+        for rep in range(2):  # the buffers are reused call after call, exactly as bench.py's rows mode does
+            _FakeEngine(truth + rep).render_packed(*g.strip, None, g.full)
+            ok = ok and bool(torch.equal(g.gather().view(H, W * C), truth + rep))
+        ok = ok and g.even == (H % world == 0) and g.nbytes == (world - 1) * (-(-H // world)) * W * C * 4
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,C", [(2, 8, 5, 41), (2, 7, 4, 41), (3, 6, 3, 41), (3, 4, 6, 2)])
+def test_packed_strip_gather_gloo(world, H, W, C):
+    """bench.py's N > 1 step (render_packed of the rank's strip into StripGather.full, then ONE all_gather_into_tensor):
+    in place when the rows divide evenly, through the padded buffer otherwise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, H, W, C, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]

@@ -19,7 +19,7 @@ GROUPS_=(
 )
 i=0
 for g in "${GROUPS_[@]}"; do
-  timeout -k 10 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 --prewarm-ms 0 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed (see pass$i.log)"
+  timeout -k 10 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 --prewarm-ms 0 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed (see pass$i.log)"
   i=$((i+1))
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
