@@ -1251,11 +1251,34 @@ __global__ void __launch_bounds__(64 * WAVES, (PREC == GDB_PREC_F32 || LOOP || W
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
         float* ck = rec_team + (size_t)k0 * rec_stride;
         bool act; float z; float vox[4];
+#if defined(GDB_XP_STAGGER)   // experiment: first-round start offsets between the workgroups that share a CU
+        if (PREC == GDB_PREC_F32 && blockIdx.x < 1024u) {
+            const int d = __builtin_amdgcn_s_getreg(6148) % 3;  // HW_REG_HW_ID[3:0]: this wave's slot on its SIMD
+            for (int i = 0; i < d * GDB_XP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+#endif
+#if defined(GDB_XP_PRIO)
+        if (PREC == GDB_PREC_F32 && (GDB_XP_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
+#endif
         const bool any = slot_gather<PREC>(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, vox);
         STAMP(2);
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
+#if defined(GDB_XP_PRIO)
+        if (PREC == GDB_PREC_F32) {
+            if (GDB_XP_PRIO & 2) {
+                switch (__builtin_amdgcn_s_getreg(6148) % 3) {  // HW_REG_HW_ID[3:0]: this wave's slot on its SIMD
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(2); break;
+                }
+            } else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (any && !SKIPPED(a.skip, 8)) slot_mlp<PREC>(f, mfg, stage, ck, act, z, vox, lane, j, h, b_agg, b_w2, dbg);
+#if defined(GDB_XP_PRIO)
+        if (PREC == GDB_PREC_F32 && (GDB_XP_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
+#endif
     }
     STAMP(7);
     __syncthreads();
@@ -1456,13 +1479,18 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
     a.ntiles = a.nsegs;
     const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    size_t pad = 0;
+#ifdef GDB_DIAG  // diagnostic build: extra LDS per workgroup lowers the occupancy (un-contended phase times under tools/stamps.py)
+    static const size_t env_pad = getenv("GDB_FUSED_LDS_PAD") ? (size_t)atol(getenv("GDB_FUSED_LDS_PAD")) : 0;
+    pad = env_pad;
+#endif
     if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
-        e = launch_solo<PREC>(a, grid, solo_lds, st);
+        e = launch_solo<PREC>(a, grid, solo_lds + pad, st);
     } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot
         a.alias = 1;
-        if (S <= 4) e = launch_fused<false, 4, PREC>(a, grid, S, (size_t)S * per_wave, st);
-        else e = launch_fused<false, 8, PREC>(a, grid, S, (size_t)S * per_wave, st);
+        if (S <= 4) e = launch_fused<false, 4, PREC>(a, grid, S, (size_t)S * per_wave + pad, st);
+        else e = launch_fused<false, 8, PREC>(a, grid, S, (size_t)S * per_wave + pad, st);
     } else {  // more slots than waves fit: waves loop over slots, separate composite records
         const size_t fixed = sizeof(float) * (size_t)S * COMP_REC;
         int nw = S < 4 ? S : 4;

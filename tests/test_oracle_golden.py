@@ -176,3 +176,42 @@ def test_build_img_feat_matches_torch_ops(Ho, Wo, H, W):
                                                            align_corners=False).unflatten(0, (B, V))), dim=2).numpy()
     assert got.shape == ref.shape and np.array_equal(got[:, :, :Cf], ref[:, :, :Cf])
     assert np.abs(got - ref).max() <= 3e-7
+
+
+@pytest.mark.parametrize("H,W,V,C", [(16, 24, 2, 19), (8, 8, 1, 3), (12, 20, 3, 5)])
+def test_texture_mip_matches_grid_sample_witness(H, W, V, C):
+    """Independent witness for the un-pinned nvdiffrast restatement (bundle_sampler.py:355-359): with boundary_mode='clamp',
+    the lookup in ONE mip level equals torch's F.grid_sample(level, 2 uv - 1, mode='bilinear', padding_mode='border',
+    align_corners=False); the mip chain equals F.avg_pool2d(2); linear-mipmap-linear is the lerp of the two levels
+    around the (clamped) bias.  Points include the borders (uv outside [0,1]), exact texel centres and integer levels."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    tex = rng.standard_normal((V, H, W, C)).astype(np.float32)
+    pyr = oracle.build_mips(tex, 3)
+    # the chain itself: 2x2 box average = avg_pool2d
+    t = torch.from_numpy(tex).permute(0, 3, 1, 2)
+    for l in range(1, len(pyr)):
+        t = F.avg_pool2d(t, 2)
+        assert max_abs(pyr[l], t.permute(0, 2, 3, 1).numpy()) <= 1e-6
+    N = 400
+    uv = rng.uniform(-0.2, 1.2, (V, N, 2)).astype(np.float32)
+    uv[:, :8, 0] = (np.arange(8, dtype=np.float32) + 0.5) / W          # texel centres
+    uv[:, 8:12] = np.array([[0, 0], [1, 1], [0, 1], [1, 0]], np.float32)  # corners
+    L = len(pyr) - 1
+    lv = rng.uniform(-1.0, L + 1.0, (V, N)).astype(np.float32)
+    lv[:, :4] = np.arange(4, dtype=np.float32)[None] % (L + 1)           # exact integer levels
+    got = oracle.texture_mip(pyr, uv, lv)
+    grid = torch.from_numpy(2.0 * uv - 1.0)[:, :, None, :]               # (V, N, 1, 2), x then y
+    per_level = []
+    for p in pyr:
+        s = F.grid_sample(torch.from_numpy(p).permute(0, 3, 1, 2), grid, mode="bilinear", padding_mode="border", align_corners=False)
+        per_level.append(s[..., 0].permute(0, 2, 1).numpy())              # (V, N, C)
+    lc = np.clip(lv, 0, L)
+    l0 = np.floor(lc).astype(int)
+    l1 = np.minimum(l0 + 1, L)
+    fr = (lc - l0)[..., None]
+    stack = np.stack(per_level)                                          # (L+1, V, N, C)
+    vi, ni = np.meshgrid(np.arange(V), np.arange(N), indexing="ij")
+    want = stack[l0, vi, ni] * (1 - fr) + stack[l1, vi, ni] * fr
+    assert max_abs(got, want) <= 5e-6   # values up to ~4: a few fp32 ulps between two orders of the same lerps

@@ -2,10 +2,16 @@
 -DGDB_DEBUG_STAMPS).  Shares, not absolute times (the stamps' waits forbid overlaps)."""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import gdb_nerf_amd  # noqa: F401  (registers the package alias)
+from gdb_nerf_amd import build as _b
+# the diagnostic library is built beside the product one and selected for this process only
+os.environ["GDB_NERF_LIB"] = _b.build(tag="diag", extra=["-DGDB_DIAG", "-DGDB_DEBUG_STAMPS"])
 from gdb_nerf_amd import synthetic, _lib
 from gdb_nerf_amd.engine import HotPathEngine
 frame = synthetic.make_frame(512, 640, V=3, seed=0); w = synthetic.make_nerf_weights(seed=0)
 eng = HotPathEngine(max_num_samples=3, is_adaptive=True); eng.load_weights(w)
+eng.precision = 0 if "f16" in sys.argv else 1
+print("precision:", "f16" if eng.precision == 0 else "f32")
 eng.prepare({k: torch.from_numpy(v).cuda() for k, v in frame.items()})
 for _ in range(3): eng.render()
 lib = _lib.load(); lib.gdb_debug_set_buffer.argtypes = [ctypes.c_void_p]; lib.gdb_debug_set_buffer.restype = None
