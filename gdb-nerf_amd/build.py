@@ -10,7 +10,9 @@ never replace the product library; select one with the environment variable GDB_
 from __future__ import annotations
 
 import hashlib
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -27,6 +29,29 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
 # The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
 # the fused fast path lets the compiler contract.
 CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off"}
+
+
+# Kernels whose private segment may only hold register spills — never data.  The round-1 "packed f32" corruption was a
+# private-memory round trip of a weight struct; the fused kernels must keep every struct in registers.
+# k_render_fused (the c2-class schedule) must not touch scratch at all.
+NO_SCRATCH = ("k_render_fused",)
+
+
+def parse_resource_usage(text: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel: {vgprs, sgprs, scratch, occupancy, ...}}."""
+    res, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"),
+                         ("scratch_bytes_per_lane", r"ScratchSize \[bytes/lane\]: (\d+)"), ("waves_per_simd", r"Occupancy \[waves/SIMD\]: (\d+)"),
+                         ("sgpr_spill", r"SGPRs Spill: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return res
 
 
 def lib_path(tag: str = "") -> str:
@@ -61,17 +86,26 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra=()) -
     objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *extra, f"-ffp-contract={CONTRACT[src]}", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, f"-ffp-contract={CONTRACT[src]}", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+    usage = {}
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out)
+        usage[src] = parse_resource_usage(out)
+        rest = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and "remark:" not in l)
+        if verbose and rest.strip():
+            print(rest)
+    with open(os.path.join(objdir, "resource_usage.json"), "w") as f:
+        json.dump(usage, f, indent=1)
+    if "-DGDB_XP_PK=1" not in extra:  # (the in-tree reproducer of the private-memory corruption is the one build allowed to)
+        bad = {k: v for u in usage.values() for k, v in u.items() if any(n in k for n in NO_SCRATCH) and v.get("scratch_bytes_per_lane", 0) > 0}
+        if bad:
+            raise RuntimeError(f"kernels that must keep their data in registers use private memory: {bad}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -385,7 +385,26 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsign
     return t;
 }
 __device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
+#ifdef GDB_XP_PK  // Reproducer kept in-tree (tools/ab_flags.sh "-DGDB_XP_PK=1" "-DGDB_XP_PK=2"; profiles/r02/ab_packed_f32_scratch_vs_registers.txt).
+    // The "packed f32 corrupts lanes 48..63" finding of round 1 is NOT a packed-math hazard: with the tap accumulate written as
+    // two v_pk_fma_f32, hipcc stops promoting the Taps / RgbTaps weight structs to registers and forms the op_sel operand pairs
+    // (w00,w10) (w10,w01) (w01,w11) with overlapping, 4-byte-aligned scratch_load_dwordx2 of the struct in PRIVATE MEMORY, right
+    // behind a lane-masked scratch_store_dwordx3/x4 (.private_segment_fixed_size 40, no spill).  That private-memory round trip
+    // returns stale lanes at full occupancy (variant 1 fails test_fused_matches_unfused_at_full_size with errors 0.25-0.6);
+    // variant 2 has the same 30 packed FMAs at the same place with the pairs built in registers (scratch size 0) and passes
+    // every parity and determinism test.  tests/test_build_resources.py keeps every product kernel's scratch data-free.
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v lo = {o.x, o.y}, hi = {o.z, o.w};
+#if GDB_XP_PK == 2  // the weight made opaque: the {w, w} pair must be built in registers (in variant 1 hipcc keeps
+    // the Taps struct in PRIVATE MEMORY and forms the op_sel pairs with overlapping 8-byte scratch loads of it)
+    asm volatile("" : "+v"(w));
+#endif
+    const f2v alo = {a.x, a.y}, ahi = {a.z, a.w}, ww = {w, w};
+    lo = __builtin_elementwise_fma(alo, ww, lo); hi = __builtin_elementwise_fma(ahi, ww, hi);
+    o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+#else
     o.x = fmaf(a.x, w, o.x); o.y = fmaf(a.y, w, o.y); o.z = fmaf(a.z, w, o.z); o.w = fmaf(a.w, w, o.w);
+#endif
 }
 // The fetch is split into "issue the loads" and "accumulate" so a view's loads can all be in flight before the
 // first one is consumed (one memory round trip instead of one per block).
@@ -1251,34 +1270,11 @@ __global__ void __launch_bounds__(64 * WAVES, (PREC == GDB_PREC_F32 || LOOP || W
     } else {  // one slot per wave: straight-line code, nothing to hoist out of a loop
         float* ck = rec_team + (size_t)k0 * rec_stride;
         bool act; float z; float vox[4];
-#if defined(GDB_XP_STAGGER)   // experiment: first-round start offsets between the workgroups that share a CU
-        if (PREC == GDB_PREC_F32 && blockIdx.x < 1024u) {
-            const int d = __builtin_amdgcn_s_getreg(6148) % 3;  // HW_REG_HW_ID[3:0]: this wave's slot on its SIMD
-            for (int i = 0; i < d * GDB_XP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-#endif
-#if defined(GDB_XP_PRIO)
-        if (PREC == GDB_PREC_F32 && (GDB_XP_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
-#endif
         const bool any = slot_gather<PREC>(f, stage, ck, tc, rng, k0, bi, row, x, inrow, j, h, a.skip, act, z, vox);
         STAMP(2);
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
-#if defined(GDB_XP_PRIO)
-        if (PREC == GDB_PREC_F32) {
-            if (GDB_XP_PRIO & 2) {
-                switch (__builtin_amdgcn_s_getreg(6148) % 3) {  // HW_REG_HW_ID[3:0]: this wave's slot on its SIMD
-                    case 0: __builtin_amdgcn_s_setprio(0); break;
-                    case 1: __builtin_amdgcn_s_setprio(1); break;
-                    default: __builtin_amdgcn_s_setprio(2); break;
-                }
-            } else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
         if (any && !SKIPPED(a.skip, 8)) slot_mlp<PREC>(f, mfg, stage, ck, act, z, vox, lane, j, h, b_agg, b_w2, dbg);
-#if defined(GDB_XP_PRIO)
-        if (PREC == GDB_PREC_F32 && (GDB_XP_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
-#endif
     }
     STAMP(7);
     __syncthreads();
@@ -1309,36 +1305,27 @@ __global__ void __launch_bounds__(64 * WAVES, (PREC == GDB_PREC_F32 || LOOP || W
 // slot and the composite pass, and a frame's waves fit on the chip in fewer rounds (c2: 2560 waves, one round).
 // Lane (j, h) owns blended channels 16h..16h+15 and feat_head channels 4h..4h+3 of bundle j; transmittance, weight
 // sum and depth are kept by both halves.  utils.py:35-41 (weights), :109-119 (sums), network.py:83-89 (depth).
-template <int PREC>
-__global__ void __launch_bounds__(64, PREC == GDB_PREC_F32 ? 2 : 3) k_render_solo(FusedArgs a_) {
+// WPS = waves per SIMD the register allocation is held to: 3 where LDS admits 12 waves per CU (V <= 3 at f16), else 2.
+template <int PREC, int WPS>
+__global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     float* stage = (float*)smem4;  // V x stage_v floats; reused for the output transpose at the end
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    // Everything wave-uniform (kernel arguments, camera block, pointers) is re-derived inside each slot iteration from
-    // an opaque pointer to the kernel arguments: as loop invariants they would be live across the whole loop body and
-    // the compiler spills ~130 SGPRs and ~50 VGPRs around every slot.  Only the composite state lives across slots.
+    // Everything wave-uniform (kernel arguments, camera block, pointers) AND the bundle itself (its ranges, its sample count)
+    // is re-derived inside each slot iteration from an opaque pointer to the kernel arguments: as loop invariants they would
+    // be live across the whole loop body, and only the composite state (22 registers) may live across slots if the body is
+    // to keep its 3 waves per SIMD without spilling.
     // (the kernel-argument segment itself, constant address space: &a_ would be a private copy of the struct)
     typedef const FusedArgs __attribute__((address_space(4))) KArgs;
     KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    int cnt, seg, row, bi;
-    float rng[4];
+    int seg, row, bi;
     {
         const FusedArgs& a = *(const FusedArgs*)ap;
-        const DevFrame& f = a.f;
         const int chunk = (a.ntiles + 7) >> 3;  // XCD-aware tile order, as above
         const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         if (tile >= a.ntiles) return;
         seg = tile % a.nseg;
         const int rr = tile / a.nseg;
         row = a.row_begin + rr % a.nrows; bi = rr / a.nrows;
-        const int x = seg * 32 + j;
-        load_ranges(f, bi, row, min(x, f.W - 1), rng);
-        float tc[TAR_STRIDE];
-        const kfloat* tcg = kptr(tar_cam(f, bi));
-#pragma unroll
-        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
-        Bundle<4> q0;
-        load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q0, rng);
-        cnt = x < f.W ? q0.count : 0;
     }
     float oacc[16], of[4], dz = 0.f, T = 1.f, wsum = 0.f;
 #pragma unroll
@@ -1347,8 +1334,6 @@ __global__ void __launch_bounds__(64, PREC == GDB_PREC_F32 ? 2 : 3) k_render_sol
     for (int i = 0; i < 4; ++i) of[i] = 0.f;
     const int S = ap->f.S_max;
     for (int k = 0; k < S; ++k) {
-        const bool act = k < cnt;
-        if (!__any(act)) break;  // a bundle's samples are slots 0..count-1: nothing left in this segment
         KArgs* apk = ap;
         asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
         const FusedArgs& a = *(const FusedArgs*)apk;
@@ -1363,14 +1348,14 @@ __global__ void __launch_bounds__(64, PREC == GDB_PREC_F32 ? 2 : 3) k_render_sol
 #pragma unroll
             for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
         }
+        Bundle<4> q;  // recomputed per slot (ranges re-read: an L1 hit): cheaper than ~30 registers live across the loop
+        load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q);
+        const bool act = x < f.W && k < q.count;
+        if (!__any(act)) break;  // a bundle's samples are slots 0..count-1: nothing left in this segment
         const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
         const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
         float z; float vox[4];
-        {
-            Bundle<4> q;  // recomputed per slot from the pre-loaded ranges: cheaper than ~24 registers live across the loop
-            load_bundle<4, true>(f, tc, bi, row, min(x, f.W - 1), q, rng);
-            slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
-        }
+        slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
         float bacc[16], fhv[4], sig;
@@ -1445,12 +1430,12 @@ static hipError_t allow_big_lds(K kernel, std::atomic<unsigned long long>& done)
     return e;
 }
 
-template <int PREC>
+template <int PREC, int WPS>
 static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
-    hipError_t e = allow_big_lds(k_render_solo<PREC>, done);
+    hipError_t e = allow_big_lds(k_render_solo<PREC, WPS>, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_render_solo<PREC>, dim3(grid), dim3(64), lds, st, a);
+    hipLaunchKernelGGL((k_render_solo<PREC, WPS>), dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -1469,7 +1454,7 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     const size_t per_wave = sizeof(float) * (size_t)V * stage_v<PREC>();
     const size_t lds_max = 160 * 1024;
     const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
-    hipError_t e;
+    hipError_t e = hipSuccess;
     // Two schedules (measured on MI355X, profiles/r01/schedules.txt):
     //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
     //                  most slots hold a sample: S_max = 3 (c2, 80 % of the lanes active: 62 vs 72 us; c3 105 vs 126 us).
@@ -1486,7 +1471,11 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
 #endif
     if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
-        e = launch_solo<PREC>(a, grid, solo_lds + pad, st);
+        // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
+        bool three = false;
+        if constexpr (PREC == GDB_PREC_F16) three = 12 * (solo_lds + pad) <= lds_max;
+        if constexpr (PREC == GDB_PREC_F16) { if (three) e = launch_solo<GDB_PREC_F16, 3>(a, grid, solo_lds + pad, st); }
+        if (!three) e = launch_solo<PREC, 2>(a, grid, solo_lds + pad, st);
     } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot
         a.alias = 1;
         if (S <= 4) e = launch_fused<false, 4, PREC>(a, grid, S, (size_t)S * per_wave + pad, st);
