@@ -220,7 +220,7 @@ def main():
                     help="untimed steps run for this long before the W warm-up steps, so clocks have ramped (0 = off)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="arithmetic of the NeRF MLP in the fused kernel")
-    ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave")
+    ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -386,7 +386,8 @@ def main():
     ab = alg_bytes(Ho, Wo, V) * share
     af = alg_flops(n_samples, V) * share
     if args.path == "fused":
-        kname = "k_render_fused" if (args.schedule == 1 or (args.schedule == 0 and wl["S"] <= 3)) else "k_render_solo"
+        auto = 3 if (wl["adaptive"] and wl["S"] > 3) else (1 if wl["S"] <= 3 else 2)   # GDB_SCHED_AUTO's rule (gdb_fused.hip render_launch)
+        kname = {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense"}[args.schedule or auto]
     else:
         kname = "k_mlp"
         ab = 4.0 * n_samples * (V * eng.P + 8 + 1 + eng.Q) + 4 * 11930  # what that kernel must read + write

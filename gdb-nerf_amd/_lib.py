@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
 ABI_VERSION = 2
 PREC_F16, PREC_F32 = 0, 1
-SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE = 0, 1, 2
+SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8
@@ -44,6 +44,7 @@ _SIGNATURES = {
     "gdb_last_error": (C.c_char_p, []),
     "gdb_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_pyramid_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
+    "gdb_dense_plan_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_packed_weight_floats": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
     "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),

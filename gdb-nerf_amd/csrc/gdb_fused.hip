@@ -1415,6 +1415,155 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dense schedule (GDB_SCHED_DENSE): the reference's flat, compacted sample list (bundle_sampler.py:182-189) cut into waves.
+// One wave = one window of a bundle-map row: the consecutive bundles whose first sample offset falls into [L w, L (w + 1)),
+// L = 33 - S_max, which together hold at most 32 samples (the plan, built by k_prepare, names each window's first bundle).
+// Lane (j, h): j = sample of the window (bundle-major, sample-minor, exactly the reference's order), h = half as everywhere.
+// Every lane carries a sample (but for the window's tail), where the slot schedules leave a lane idle whenever its bundle
+// has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy, c4 64 % -> 88 %.
+// The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by
+// looking back over the earlier samples, weighted sums by a segmented suffix sum in log2(S_max) shuffle steps, the bundle's
+// first lane normalises and hands the row to the LDS transpose.  utils.py:35-41, :109-119, network.py:83-89.
+template <int PREC, int WPS>
+__global__ void __launch_bounds__(64, WPS) k_render_dense(FusedArgs a) {
+    const DevFrame& f = a.f;
+    float* stage = (float*)smem4;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    unsigned* dbg = a.dbg; (void)dbg;
+    const int chunk = (a.ntiles + 7) >> 3;  // XCD-aware tile order: one contiguous band of (row, window) tiles per XCD
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile >= a.ntiles) return;
+    const int win = tile % f.planMW, rr = tile / f.planMW;
+    const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
+    const int* rec = f.plan + (size_t)(bi * f.H + row) * (f.planMW + 2);
+    typedef const int __attribute__((address_space(4))) kint;  // written by k_prepare, an earlier launch: scalar loads
+    const kint* krec = (const kint*)rec;
+    if (win >= krec[0]) return;  // the grid is sized for the worst case (every bundle at S_max); surplus windows leave at once
+    // this window's bundles: first .. first + nb - 1, nb <= 32.  Clamped, so that a plan that does not belong to this frame
+    // (gdb_prepare not run on it) renders garbage instead of reading outside the frame.
+    const int first = min(max(krec[1 + win], 0), f.W - 1);
+    const int nb = min(max(krec[2 + win] - first, 0), min(32, f.W - first));
+    float tc[TAR_STRIDE];
+    {
+        const kfloat* tcg = kptr(tar_cam(f, bi));
+#pragma unroll
+        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
+    }
+    STAMP(0);
+    // ---- lane j as BUNDLE first + j: its sample count and the offset of its first sample inside the window --------------
+    int cnt_b = 0;
+    if (j < nb) {
+        float r[4];
+        load_ranges(f, bi, row, first + j, r);
+        float n0 = r[0], f0 = r[1];
+        if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
+        cnt_b = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
+    }
+    int incl = cnt_b;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 32); if (j >= d) incl += t; }
+    const int total = min(__shfl(incl, 31, 32), 32);  // samples in this window (<= 32 by construction of the plan)
+    // sample -> (bundle, slot) map through LDS (the staging area is not in use yet)
+    int* smap = (int*)stage;
+    if (h == 0)
+        for (int k = 0; k < cnt_b; ++k)
+            if (incl - cnt_b + k < 32) smap[incl - cnt_b + k] = j | (k << 8);
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    // ---- lane j as SAMPLE j of the window -------------------------------------------------------------------------------
+    const bool act = j < total;
+    const int m = smap[act ? j : 0];
+    const int bj = m & 255, k = m >> 8;
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
+    const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
+    float z; float vox[4];
+    int cnt;
+    {
+        Bundle<4> q;
+        load_bundle<4, true>(f, tc, bi, row, first + bj, q);
+        cnt = q.count;
+        STAMP(1);
+        slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
+    }
+    STAMP(2);
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    float v[22];  // 0..15 blended channels 16h.., 16..19 feat_head 4h.., 20 weight, 21 weight x depth
+    float sig;
+    {
+        float bacc[16], fhv[4];
+        if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        else slot_mlp_core(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = bacc[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[16 + i] = fhv[i];
+    }
+    // ---- composite across the lanes of a bundle --------------------------------------------------------------------------
+    const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
+    float Tr = 1.f;
+    const int S = f.S_max;
+    for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
+        const float ap = __shfl_up(al, d, 32);
+        if (d <= k) Tr *= 1.f - ap;
+    }
+    const float w = al * Tr;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
+    v[20] = w;
+    v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
+    for (int d = 1; d < S; d <<= 1) {  // segmented suffix sums: afterwards the bundle's first lane (k == 0) holds the bundle's sums
+        const bool take = act && k + d < cnt;
+#pragma unroll
+        for (int i = 0; i < 22; ++i) {
+            const float t = __shfl_down(v[i], d, 32);
+            if (take) v[i] += t;
+        }
+    }
+    STAMP(7);
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity; column = bundle of the window
+    if (act && k == 0) {
+        const float rden = 1.f / fmaxf(v[20], 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int c = 16 * h + i;
+            if (c < NBLEND) o[c * COMP_LD + bj] = v[i] * rden;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + bj] = v[16 + i] * rden;
+        if (h == 0) {
+            const float d = v[21] * rden;
+            o[NOUT * COMP_LD + bj] = f.inv_depth ? 1.f / d : d;  // network.py:88-89
+            o[(NOUT + 1) * COMP_LD + bj] = v[20] * rden;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)first;
+    if (a.ldo == NOUT) {
+        for (int qi = lane; qi < nb * NOUT; qi += 64) {
+            int jj = qi / NOUT, c = qi - jj * NOUT;
+            a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
+        }
+        if (j < nb) {
+            if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
+            else a.depth[b0 + j] = o[NOUT * COMP_LD + j];
+        }
+    } else {  // packed rows [feat | depth | opacity]
+        constexpr int LDO = NOUT + 2;
+        for (int qi = lane; qi < nb * LDO; qi += 64) {
+            int jj = qi / LDO, c = qi - jj * LDO;
+            a.bf[b0 * LDO + qi] = o[c * COMP_LD + jj];
+        }
+    }
+    STAMP(8); STAMP(9);
+}
+
 // LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
 // function: the once-flag is a bit per device ordinal (relaxed atomics; setting it twice is harmless).
 #include <atomic>
@@ -1436,6 +1585,15 @@ static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hip
     hipError_t e = allow_big_lds(k_render_solo<PREC, WPS>, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_render_solo<PREC, WPS>), dim3(grid), dim3(64), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int PREC, int WPS>
+static hipError_t launch_dense(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS>, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_render_dense<PREC, WPS>), dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -1463,13 +1621,26 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     const bool want_solo = sched == GDB_SCHED_SEGMENT_WAVE || (sched == GDB_SCHED_AUTO && S > 3);
     const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
     a.ntiles = a.nsegs;
-    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
     size_t pad = 0;
 #ifdef GDB_DIAG  // diagnostic build: extra LDS per workgroup lowers the occupancy (un-contended phase times under tools/stamps.py)
     static const size_t env_pad = getenv("GDB_FUSED_LDS_PAD") ? (size_t)atol(getenv("GDB_FUSED_LDS_PAD")) : 0;
     pad = env_pad;
 #endif
-    if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
+    // Dense: the compacted sample list, one wave per <= 32 consecutive samples (needs the plan gdb_prepare builds from the
+    // depth prior).  Taken for adaptive counts, where the slot schedules leave lanes idle.
+    // (measured on MI355X, profiles/r02/schedules.txt: c4, S_max 6 adaptive, 64 % of the slot lanes busy: 132 vs 158 us f16,
+    // 283 vs 397 us f32; c2, S_max 3, 80 % busy: 67 vs 59 us f16, 139 vs 133 us f32 — the slot waves stay for S_max <= 3)
+    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && S > 3);
+    if (want_dense && solo_lds <= lds_max) {
+        a.alias = 0;
+        a.ntiles = fr->B * a.nrows * a.f.planMW;
+        grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+        bool three = false;
+        if constexpr (PREC == GDB_PREC_F16) three = 12 * (solo_lds + pad) <= lds_max;
+        if constexpr (PREC == GDB_PREC_F16) { if (three) e = launch_dense<GDB_PREC_F16, 3>(a, grid, solo_lds + pad, st); }
+        if (!three) e = launch_dense<PREC, 2>(a, grid, solo_lds + pad, st);
+    } else if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
         // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
         bool three = false;
@@ -1502,7 +1673,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
     if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32)
         return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA)", precision);
-    if (schedule < 0 || schedule > 2) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..2", schedule);
+    if (schedule < 0 || schedule > 3) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..3", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
     if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);

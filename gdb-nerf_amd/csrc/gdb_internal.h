@@ -66,9 +66,10 @@ struct WsLayout {
     int lvlH[GDB_MAX_MIP + 1], lvlW[GDB_MAX_MIP + 1];
     size_t lvlOff[GDB_MAX_MIP + 1];  // float offset of each level inside one (b,v) pyramid
     size_t pyrStride;                // floats per (b,v) pyramid
-    size_t camsOff, pyrOff, cntOff, offOff, bsumOff;  // byte offsets in the workspace
+    size_t camsOff, pyrOff, cntOff, offOff, bsumOff, planOff;  // byte offsets in the workspace
     size_t total;
     int nBlocksScan;
+    int planL, planMW;  // dense schedule: sample-offset window length, windows per bundle-map row at most (plan row = planMW + 2 ints)
 };
 
 #define SCAN_BLOCK 1024
@@ -97,6 +98,12 @@ static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
     L.cntOff = off;  off = align_up(off + sizeof(int32_t) * nb, 256);
     L.offOff = off;  off = align_up(off + sizeof(int32_t) * nb, 256);
     L.bsumOff = off; off = align_up(off + sizeof(int32_t) * (L.nBlocksScan + 1), 256);
+    // Dense-schedule plan (k_prepare writes it, k_render_dense reads it): per bundle-map row the first bundle of every window of
+    // planL consecutive sample offsets.  A bundle holds at most S_max <= planL samples, so every window has a first bundle, and a
+    // window's bundles hold at most planL + S_max - 1 = 32 samples: one wave's lanes.
+    L.planL = 33 - c.max_num_samples;
+    L.planMW = (int)(((size_t)f.W * c.max_num_samples + L.planL - 1) / L.planL);
+    L.planOff = off; off = align_up(off + sizeof(int32_t) * (size_t)f.B * f.H * (L.planMW + 2), 256);
     L.total = off;
     return L;
 }
@@ -109,6 +116,8 @@ struct DevFrame {
     unsigned lvlOff[GDB_MAX_MIP + 1];
     unsigned pyrStride;
     float invW, invH;  // 1/W, 1/H of the bundle map (uniform reciprocals the fused kernel would otherwise recompute per view)
+    int planL, planMW;
+    const int* plan;   // dense-schedule plan rows: [nwin, first bundle of window 0..nwin-1, W]
     const float* cams;
     const float* pyr;
     const float* src_images;
@@ -124,6 +133,8 @@ static inline DevFrame dev_frame(const GdbConfig& c, const GdbFrame& f, const Ws
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { d.lvlH[i] = L.lvlH[i]; d.lvlW[i] = L.lvlW[i]; d.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     d.pyrStride = (unsigned)L.pyrStride;
     d.invW = 1.f / (float)f.W; d.invH = 1.f / (float)f.H;
+    d.planL = L.planL; d.planMW = L.planMW;
+    d.plan = (const int*)((const char*)ws + L.planOff);
     d.cams = (const float*)((const char*)ws + L.camsOff);
     d.pyr = (const float*)((const char*)ws + L.pyrOff);
     d.src_images = f.d_src_images; d.feat_volume = f.d_feat_volume;

@@ -82,6 +82,15 @@ extern "C" int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, 
     return GDB_OK;
 }
 
+extern "C" int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[3]) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
+    if (!out) return gdb_fail(GDB_E_BADARG, "out is NULL");
+    const WsLayout L = ws_layout(*cfg, *shape);
+    out[0] = L.planOff; out[1] = (size_t)L.planMW + 2; out[2] = (size_t)L.planL;
+    return GDB_OK;
+}
+
 extern "C" int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
@@ -193,7 +202,50 @@ struct PrepArgs {
     const float* src_images; int Ho, Wo, fpn;  // fpn: img_feat holds C_f channels only; the 3 colours are resampled here (N3)
     const float* tar_exts; const float* tar_ints; const float* src_exts; const float* src_ints; const float* near_far;
     float* cams;
+    // dense-schedule plan: workgroups ntiles+1 .. ntiles+nplan, one wave per bundle-map row
+    int nplan, S_max, adaptive, planL, planMW;
+    const float* depth_range; int* plan;
 };
+
+// One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, and for
+// every window of planL consecutive sample offsets the first bundle whose offset falls into it.  Row record: [number of windows,
+// first bundle of window 0 .. nwin-1, W].  Lane l takes the bundles [l * cpl, (l+1) * cpl) of the row.
+__device__ void plan_row(const PrepArgs& a, int rowid, int lane) {
+    const int bi = rowid / a.H, row = rowid % a.H;
+    const float nr = a.near_far[bi * 2], fr = a.near_far[bi * 2 + 1];
+    const float miniv = a.inv_depth ? (1.f / nr - 1.f / fr) / (float)a.gnd : (fr - nr) / (float)a.gnd;  // = T_MINIV of the camera block
+    const size_t hw = (size_t)a.H * a.W;
+    const float* nearp = a.depth_range + ((size_t)bi * 2) * hw + (size_t)row * a.W;
+    const float* farp = nearp + hw;
+    const int cpl = (a.W + 63) / 64;
+    const int x0 = lane * cpl, x1 = min(a.W, x0 + cpl);
+    auto count_at = [&](int x) {
+        float n0 = nearp[x], f0 = farp[x];
+        if (a.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }  // bundle_sampler.py:224-226, as load_bundle does
+        return sample_count(n0, f0, miniv, a.S_max, a.adaptive);
+    };
+    int sum = 0, lastc = 0;
+    for (int x = x0; x < x1; ++x) { lastc = count_at(x); sum += lastc; }
+    int incl = sum;  // inclusive prefix over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, 63);
+    int off = incl - sum;                       // sample offset of this lane's first bundle
+    int cprev = __shfl_up(lastc, 1);            // count of the bundle just before it
+    if (lane == 0) cprev = 0;
+    int* rec = a.plan + (size_t)rowid * (a.planMW + 2);
+    (void)total;
+    for (int x = x0; x < x1; ++x) {
+        const int w = off / a.planL;
+        // consecutive bundle offsets differ by at most S_max <= planL, so every window up to the one the LAST bundle starts in
+        // has a first bundle; windows beyond that one hold no bundle start (the last bundle's samples may reach into the next
+        // window of offsets — they still belong to the window the bundle starts in)
+        if (x == 0 || (off - cprev) / a.planL != w) rec[1 + w] = x;
+        if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = a.W; }
+        cprev = count_at(x);
+        off += cprev;
+    }
+}
 
 __device__ __forceinline__ float4 box4(const float4 A, const float4 B, const float4 C, const float4 D) {
     return make_float4((A.x + B.x + C.x + D.x) * 0.25f, (A.y + B.y + C.y + D.y) * 0.25f,
@@ -205,6 +257,11 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
 
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
+    if ((int)blockIdx.x > a.ntiles) {  // dense-schedule plan: 4 rows per workgroup
+        const int rowid = ((int)blockIdx.x - a.ntiles - 1) * 4 + (int)(threadIdx.x >> 6);
+        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
+        return;
+    }
     if ((int)blockIdx.x >= a.ntiles) {
         for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
             if (t % (a.V + 1) == 0 || a.src_exts)
@@ -317,7 +374,11 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     a.fpn = fpn_feat != nullptr; a.src_images = f->d_src_images; a.Ho = f->Ho; a.Wo = f->Wo;
     a.tar_exts = f->d_tar_exts; a.tar_ints = f->d_tar_ints; a.src_exts = f->d_src_exts; a.src_ints = f->d_src_ints;
     a.near_far = f->d_near_far; a.cams = (float*)((char*)ws + L.camsOff);
-    hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1), dim3(256), 0, st, a);
+    // the dense schedule's plan needs the depth prior; a frame prepared without it (build_rays / sample only) has none
+    a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
+    a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
+    a.nplan = f->d_depth_range ? (f->B * f->H + 3) / 4 : 0;
+    hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;
 }

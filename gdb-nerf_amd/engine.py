@@ -196,9 +196,10 @@ class HotPathEngine:
 
     def set_schedule(self, mode: int) -> None:
         """Work decomposition of THIS engine's fused calls (a per-call argument of the C ABI, no process-wide state):
-        0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment.  See include/gdb_nerf_hip.h."""
-        if int(mode) not in (0, 1, 2):
-            raise ValueError(f"schedule {mode} outside 0..2")
+        0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment, 3 dense (one wave per <= 32 consecutive samples
+        of the compacted sample list).  See include/gdb_nerf_hip.h."""
+        if int(mode) not in (0, 1, 2, 3):
+            raise ValueError(f"schedule {mode} outside 0..3")
         self.schedule = int(mode)
 
     def feature_pyramid(self):
@@ -216,6 +217,17 @@ class HotPathEngine:
             lv = pyr[:, out[3 + l]:out[3 + l] + 20 * h * w].reshape(n, 5, h, w, 4)       # [chunk][y][x][4]
             res.append(lv.permute(0, 2, 3, 1, 4).reshape(f.B, f.V, h, w, 20)[..., :19].contiguous())
         return res
+
+    def dense_plan(self) -> torch.Tensor:
+        """The dense schedule's plan `prepare` built from the depth prior: (B*H, stride) int32, row = [n_windows, first bundle of
+        each window, W]; plus the window length L as `.window` attribute.  See include/gdb_nerf_hip.h gdb_dense_plan_layout."""
+        f = self._need_frame()
+        out = (C.c_size_t * 3)()
+        _lib.check(self.lib.gdb_dense_plan_layout(C.byref(self.cfg), C.byref(f), out))
+        rows = f.B * f.H
+        t = self._ws[out[0]:out[0] + 4 * rows * out[1]].view(torch.int32).view(rows, out[1]).clone()
+        t.window = int(out[2])
+        return t
 
     def _need_frame(self) -> GdbFrame:
         if self._frame is None:

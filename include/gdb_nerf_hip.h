@@ -95,6 +95,13 @@ int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out
  * an odd extent), out[3 + l] = float offset of level l inside one pyramid, l = 0..3. */
 int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]);
 
+/* Where gdb_prepare() puts the plan of the dense schedule (GDB_SCHED_DENSE), for callers / tests that want to read it: per
+ * bundle-map row (B*H rows) out[1] int32 values [n_windows, first bundle of window 0 .. n_windows-1, W]; a window is the run of
+ * consecutive bundles whose first sample offset inside the row (exclusive prefix of the per-bundle sample counts,
+ * bundle_sampler.py:179-189) falls into [out[2] * w, out[2] * (w + 1)) — at most 32 samples.  out[0] = byte offset of the
+ * first row record.  Built only when the frame handed to gdb_prepare carries d_depth_range. */
+int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[3]);
+
 /* ---- MLP weights -------------------------------------------------------------------- */
 /* Number of floats in the packed weight buffer for cfg (fp32 section + MFMA-fragment
  * section). */
@@ -193,7 +200,9 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *                 the reference's own precision.
  * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
- *   its 32 bundles with the composite in registers.
+ *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
+ *   (bundle_sampler.py:182-189): one wave per <= 32 consecutive samples of a bundle-map row, composite across lanes
+ *   (uses the per-row plan gdb_prepare builds from d_depth_range).
  * Both are per-call arguments: the library keeps no process-global state (two engines with different settings may
  * interleave calls on different streams or threads).
  * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
@@ -202,6 +211,7 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
 #define GDB_SCHED_AUTO 0
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2
+#define GDB_SCHED_DENSE 3
 int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
                              const float* d_packed_weights, int32_t row_begin, int32_t row_end,
                              int32_t precision, int32_t schedule, float* d_bundle_feat, float* d_depth,

@@ -31,9 +31,10 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(params=[(1, 0), (2, 0), (1, 1), (2, 1)], ids=["slot-waves-f16", "segment-wave-f16", "slot-waves-f32", "segment-wave-f32"])
+@pytest.fixture(params=[(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)],
+                ids=["slot-waves-f16", "segment-wave-f16", "dense-f16", "slot-waves-f32", "segment-wave-f32", "dense-f32"])
 def mode(request):
-    """(schedule, precision): both work decompositions of the fused kernel x both MLP precisions
+    """(schedule, precision): the three work decompositions of the fused kernel x both MLP precisions
     (include/gdb_nerf_hip.h GDB_SCHED_*, GDB_PREC_*).  Per-engine settings, passed on every call of the C ABI."""
     return request.param
 
@@ -363,7 +364,7 @@ def test_c2_full_size_against_the_oracle():
     eu = max_abs(npy(ubf), obf)
     print(f"c2 512x640 vs oracle: fp32 operator chain max abs err {eu:.3e}")
     assert eu <= 2e-4 and max_abs(npy(ud), od) <= 1e-4 * float(np.abs(od).max()) and max_abs(npy(uo), oo) <= 1e-5
-    for sched in (1, 2):
+    for sched in (1, 2, 3):
         for prec, tol in ((1, FUSED_TOL_F32), (0, FUSED_TOL)):
             eng.set_schedule(sched)
             bf, depth, opac = eng.render(precision=prec)
@@ -421,12 +422,13 @@ def test_fused_schedules_agree_and_reject_bad_mode(prec):
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=4), max_num_samples=5, is_adaptive=True)
     eng.precision = prec
     eng.set_schedule(1); a = [t.clone() for t in eng.render()]
-    eng.set_schedule(2); b = [t.clone() for t in eng.render()]
-    assert max_abs(npy(a[0]), npy(b[0])) <= 2e-6
-    assert max_abs(npy(a[1]), npy(b[1])) <= 2e-6 * float(a[1].abs().max())
-    assert max_abs(npy(a[2]), npy(b[2])) <= 2e-6
+    for other in (2, 3):
+        eng.set_schedule(other); b = [t.clone() for t in eng.render()]
+        assert max_abs(npy(a[0]), npy(b[0])) <= 2e-6
+        assert max_abs(npy(a[1]), npy(b[1])) <= 2e-6 * float(a[1].abs().max())
+        assert max_abs(npy(a[2]), npy(b[2])) <= 2e-6
     with pytest.raises(ValueError, match="schedule"):
-        eng.set_schedule(3)
+        eng.set_schedule(4)
     eng.schedule = 7  # past the Python check: the C ABI rejects it before any launch
     with pytest.raises(ValueError, match="schedule"):
         eng.render()
@@ -435,12 +437,39 @@ def test_fused_schedules_agree_and_reject_bad_mode(prec):
         eng.render(precision=2)
 
 
+@pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),
+                                                          (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu")])
+def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
+    """The plan of the dense schedule (k_prepare): for every bundle-map row the windows are consecutive, non-empty runs of
+    bundles covering the row, each holding at most 32 samples, and window w starts at the first bundle whose sample offset
+    (exclusive prefix of the oracle's per-bundle counts) reaches L * w."""
+    frame = synthetic.make_frame(Ho, Wo, V=2, B=B, scene=scene, seed=17)
+    eng = engine_for(frame, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    H, W = Ho // 2, Wo // 2
+    rays = oracle_rays(frame)
+    smp = oracle.sample_bundles(rays, frame["depth_range"], frame["vol_range"], frame["near_far"][:, 0], frame["near_far"][:, 1], 2, S, 64,
+                                inv_depth=inv, adaptive=adaptive)
+    cnt = np.asarray(smp["samples_per_bundle"]).astype(np.int64).reshape(B * H, W)
+    plan = npy(eng.dense_plan())
+    L = eng.dense_plan().window
+    assert L == 33 - S
+    for r in range(B * H):
+        nwin = int(plan[r, 0])
+        firsts = plan[r, 1:2 + nwin]
+        assert firsts[0] == 0 and firsts[-1] == W and np.all(np.diff(firsts) > 0)
+        off = np.concatenate(([0], np.cumsum(cnt[r])[:-1]))
+        for w in range(nwin):
+            a, b = int(firsts[w]), int(firsts[w + 1])
+            assert cnt[r, a:b].sum() <= 32 and b - a <= 32
+            assert off[a] >= L * w and (a == 0 or off[a - 1] < L * w) and off[b - 1] < L * (w + 1)
+
+
 def test_engines_with_different_settings_interleave():
     """the ABI is reentrant — no process-global state.  Four engines (both schedules x both precisions)
     on two HIP streams, their calls interleaved, must each reproduce their solo result bit for bit."""
     frames = [synthetic.make_frame(128, 160, V=3, seed=40 + i) for i in range(4)]
     w = synthetic.make_nerf_weights(seed=6)
-    modes = [(1, 0), (2, 1), (2, 0), (1, 1)]
+    modes = [(1, 0), (2, 1), (3, 0), (3, 1)]
     engs = [engine_for(f, w, m, max_num_samples=4, is_adaptive=True) for f, m in zip(frames, modes)]
     solo = [[t.clone() for t in e.render()] for e in engs]
     torch.cuda.synchronize()

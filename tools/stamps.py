@@ -11,19 +11,22 @@ from gdb_nerf_amd.engine import HotPathEngine
 frame = synthetic.make_frame(512, 640, V=3, seed=0); w = synthetic.make_nerf_weights(seed=0)
 eng = HotPathEngine(max_num_samples=3, is_adaptive=True); eng.load_weights(w)
 eng.precision = 0 if "f16" in sys.argv else 1
-print("precision:", "f16" if eng.precision == 0 else "f32")
+sched = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--schedule=")), 1)
+eng.set_schedule(sched)
+print("precision:", "f16" if eng.precision == 0 else "f32", " schedule:", sched)
 eng.prepare({k: torch.from_numpy(v).cuda() for k, v in frame.items()})
 for _ in range(3): eng.render()
 lib = _lib.load(); lib.gdb_debug_set_buffer.argtypes = [ctypes.c_void_p]; lib.gdb_debug_set_buffer.restype = None
-nblk = 2560 + 8
+nblk = 16384
 dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device="cuda")
 lib.gdb_debug_set_buffer(dbg.data_ptr())
 eng.render(); torch.cuda.synchronize()
 lib.gdb_debug_set_buffer(None)
 t = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :10].reshape(-1, 10).astype(np.int64)
-t[:, 1] = t[:, 0]
+if sched != 3:
+    t[:, 1] = t[:, 0]
 t = t[(t[:, 0] > 0) & (t[:, 9] > 0)]
-names = ["(unused)", "bundle+vox+gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
+names = ["(dense: plan + sample map)" if sched == 3 else "(unused)", "bundle+vox+gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
 full = t[t[:, 6] > 0]  # waves that ran a slot
 d = np.diff(full, axis=1).astype(np.float64)
 tot = (full[:, 9] - full[:, 0]).mean()
