@@ -354,6 +354,8 @@ def main():
         dt_rows = timed.run(step_rows, args.warmup, args.steps)
         kern_rows, ag_ms = ev_ms(kern_pairs), ev_ms(ag_pairs)
         kern_pairs.clear()
+        # untimed check: the gathered strips equal this rank's own render of the whole frame, bit for bit
+        rows_ok = bool(torch.equal(gather.full, eng.render_packed(0, H)))
         # frames mode: every rank its own frame (seeded by rank)
         frame = to_dev(synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=rank), dev)
         dt_frames = timed.run(step_frame, args.warmup, args.steps)
@@ -363,13 +365,13 @@ def main():
                     "allgather_ms": ag_ms, "allgather_bytes_per_rank": gather.nbytes,
                     "bus_GBps": (gather.nbytes / (ag_ms * 1e-3) / 1e9) if ag_ms else None,
                     "collective": "gloo (rehearsal, staged through host memory)" if rehearse else "RCCL all_gather_into_tensor, in place" if gather.even else "RCCL all_gather_into_tensor, padded",
-                    "world_size": world}
+                    "world_size": world, "gathered_equals_full_render": rows_ok}
         rec_frames = {"mode": "frames: every rank its own frame, no data-path collective", "scaling": "weak",
                       "value": world * Ho * Wo * args.steps / dt_frames, "ms_per_step": dt_frames / args.steps * 1e3, "kernel_ms": kern_frames}
         if rows_mode:
             dt, rays_per_step, share = dt_rows, Ho * Wo, (r1 - r0) / H
             kern_pairs.clear()
-            extra.update({k: rec_rows[k] for k in ("allgather_ms", "allgather_bytes_per_rank", "bus_GBps", "collective", "world_size")})
+            extra.update({k: rec_rows[k] for k in ("allgather_ms", "allgather_bytes_per_rank", "bus_GBps", "collective", "world_size", "gathered_equals_full_render")})
             extra["independent_frames"] = rec_frames
             kern_ms_override = kern_rows
         else:
