@@ -119,7 +119,7 @@ def build_peaks(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(PEAKS_LIB) and os.path.getmtime(PEAKS_LIB) >= os.path.getmtime(PEAKS_SRC):
         return PEAKS_LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", PEAKS_SRC, "-o", PEAKS_LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-shared", PEAKS_SRC, "-o", PEAKS_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -964,19 +964,27 @@ __device__ __forceinline__ void view_g32(const Tail32& t, const f32x4 q_view, co
 }
 
 // Same contract as slot_mlp_core.  `m32` = f32-MFMA section of the packed weights (global memory, L2-resident).
+// The matrix pipe is the bound here (316 MFMAs x 64 cycles per slot at V = 3), so the weight stream must never make it wait:
+// as in the f16 core every phase first issues the loads of the NEXT phase's quads and bias tables — they fly under this phase's
+// MFMA chain — and then computes with operands loaded a phase earlier (un-contended MLP time per slot 35.4k -> see DESIGN §4.1c;
+// the phases' own loads at their start had each exposed one L2 round trip: 5.9k of the 15.1k cycles of the dense middle section).
+// How much is prefetched is set by the 168-register budget of three waves per SIMD.
 __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float* __restrict__ m32, const float* stage, const float vox[4], int lane,
                                                   int j, int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
     const int V = f.V;
     constexpr int STAGE_V = stage_v<GDB_PREC_F32>();
     f32x16 base;
     f32x4 q_view;
+    f32x16 b_view;
+    f32x4 wg[3];
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
         q_view = load_quad(m32, Q_VIEW, lane_o);
-        const f32x16 b_view = load_tab(m32, T32_VIEW, h_o);
+        b_view = load_tab(m32, T32_VIEW, h_o);
         f32x4 wv[3], wm[3];
         load_quads<12>(m32, Q_GVAR, lane_o, wv);
         load_quads<12>(m32, Q_GMEAN, lane_o, wm);
         base = load_tab(m32, T32_GLOB, h_o);
+        load_quads<12>(m32, Q_GA, lane_o, wg);  // next phase
         float mean[12], m2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
@@ -1003,11 +1011,10 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     PHASE_FENCE();
     STAMP(3);
     float agg[16];
+    f32x4 wfc[4];
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-        const f32x16 b_view = load_tab(m32, T32_VIEW, h_o);
-        f32x4 wg[3];
-        load_quads<12>(m32, Q_GA, lane_o, wg);
         const f32x16 w_agg = load_tab(m32, T32_AGG, h_o);
+        load_quads<16>(m32, Q_FC, lane_o, wfc);  // next phase: fc (its bias is added after the chain: no register to park it here)
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         float mx = -INFINITY, den = 0.f;
@@ -1031,40 +1038,62 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     }
     PHASE_FENCE();
     float hb[12];  // [vox | im] operand: steps 0..7 = ReLU(im) registers 0..7, steps 8..11 = vox
+    f32x4 wl0[3], wl1[3];
+    f32x16 x0, x1;
     {   LANE_KEYS();  // im = ReLU(fc(agg))   nerf.py:82
-        const f32x16 im = chain32<16>(m32, Q_FC, lane_o, agg, load_tab(m32, T32_FC, h_o));
+        f32x16 im;
+        load_quads<12>(m32, Q_LR0, lane_o, wl0); load_quads<12>(m32, Q_LR0 + 3, lane_o, wl1);  // next phase: lr0
+        x0 = load_tab(m32, T32_LR0, h_o); x1 = load_tab(m32, T32_LR0 + 32, h_o);
+        const f32x16 bfc = load_tab(m32, T32_FC, h_o);  // lands under the chain below
+        im = chain32w<16>(wfc, agg, zero16());
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hb[i] = relu1(im[i]);
+        for (int i = 0; i < 8; ++i) hb[i] = relu1(im[i] + bfc[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) hb[8 + i] = vox[i];
     }
     PHASE_FENCE();
     STAMP(4);
     float X[32];  // x = ReLU(lr0([vox | im])): [tile][register]   nerf.py:100-101
+    f32x4 wfh[8];
+    f32x16 fh;
     {   LANE_KEYS();
-        const f32x16 x0 = chain32<12>(m32, Q_LR0, lane_o, hb, load_tab(m32, T32_LR0, h_o));
-        const f32x16 x1 = chain32<12>(m32, Q_LR0 + 3, lane_o, hb, load_tab(m32, T32_LR0 + 32, h_o));
+        load_quads<32>(m32, Q_FH, lane_o, wfh);  // next phase: feat_head + sigma
+        fh = load_tab(m32, T32_FH, h_o);
+        x0 = chain32w<12>(wl0, hb, x0);
+        x1 = chain32w<12>(wl1, hb, x1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { X[i] = relu1(x0[i]); X[16 + i] = relu1(x1[i]); }
     }
     PHASE_FENCE();
+    f32x4 wa[8], wb[3];
+    f32x16 hs0, hs1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        const f32x16 fh = chain32<32>(m32, Q_FH, lane_o, X, load_tab(m32, T32_FH, h_o));
+        load_quads<32>(m32, Q_W0A, lane_o, wa); load_quads<12>(m32, Q_W0B, lane_o, wb);  // next phase: weight.0 rows 0..31
+        hs0 = load_tab(m32, T32_W0, h_o);
+        fh = chain32w<32>(wfh, X, fh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fhv[i] = relu1(fh[i]);
         sig = fh[4];
     }
     PHASE_FENCE();
     // shared part of weight.0: bias + columns on x and on [vox | im]   nerf.py:106-109
-    f32x16 hs0, hs1;
+    f32x4 wa2[8];
     {   LANE_KEYS();
-        hs0 = chain32<32>(m32, Q_W0A, lane_o, X, load_tab(m32, T32_W0, h_o));
-        hs0 = chain32<12>(m32, Q_W0B, lane_o, hb, hs0);
+        load_quads<24>(m32, Q_W0A + 8, lane_o, wa2);  // next phase: weight.0 rows 32..63, the first 6 of its 8 quads on x (the
+        hs1 = load_tab(m32, T32_W0 + 32, h_o);        // last two and the [vox | im] quads follow there: 168 registers = 3 waves per SIMD)
+        hs0 = chain32w<32>(wa, X, hs0);
+        hs0 = chain32w<12>(wb, hb, hs0);
     }
     PHASE_FENCE();
+    f32x4 wc0[4];  // per-view blend pass operands: loop-invariant, loaded once per slot
+    f32x16 w20;
     {   LANE_KEYS();
-        hs1 = chain32<32>(m32, Q_W0A + 8, lane_o, X, load_tab(m32, T32_W0 + 32, h_o));
-        hs1 = chain32<12>(m32, Q_W0B + 3, lane_o, hb, hs1);
+        load_quads<8>(m32, Q_W0A + 14, lane_o, wa2 + 6);
+        load_quads<12>(m32, Q_W0B + 3, lane_o, wb);
+        load_quads<14>(m32, Q_W0C, lane_o, wc0);  // next phase
+        w20 = load_tab(m32, T32_W2, h_o);
+        hs1 = chain32w<32>(wa2, X, hs1);
+        hs1 = chain32w<12>(wb, hb, hs1);
     }
     PHASE_FENCE();
     STAMP(5);
@@ -1073,10 +1102,9 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
         LANE_KEYS();
-        f32x4 wc0[4], wc1[4];  // loop-invariant: loaded once per slot
-        load_quads<14>(m32, Q_W0C, lane_o, wc0);
+        f32x4 wc1[4];
         load_quads<14>(m32, Q_W0C + 4, lane_o, wc1);
-        const f32x16 w20 = load_tab(m32, T32_W2, h_o), w21 = load_tab(m32, T32_W2 + 32, h_o);
+        const f32x16 w21 = load_tab(m32, T32_W2 + 32, h_o);
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
@@ -1216,7 +1244,7 @@ __device__ __forceinline__ void composite(const FusedArgs& a, float* rec_team, s
 // workgroup was measured 25-30 % slower (it caps the CU at 6-9 waves), see DESIGN.md.
 // PREC: GDB_PREC_F16 (f16 MFMA operands, 3 waves per SIMD) or GDB_PREC_F32 (fp32 MFMA, matrix-pipe-bound: 2 waves per SIMD).
 template <bool LOOP, int WAVES, int PREC>
-__global__ void __launch_bounds__(64 * WAVES, (PREC == GDB_PREC_F32 || LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_render_fused(FusedArgs a) {
     const DevFrame& f = a.f;
     float* smem = (float*)smem4;
     // the wave index is uniform but derived from threadIdx: without readfirstlane everything computed from it (team,

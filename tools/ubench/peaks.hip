@@ -64,3 +64,64 @@ int gdb_peak_mfma(int f16, float* sink, int blocks, int iters, void* stream) {
     return (int)hipGetLastError();
 }
 }
+
+// Do MFMAs and fp32 VALU FMAs overlap on a SIMD?  One workgroup per CU (launch 256 of them): with 256 threads each SIMD hosts one
+// wave, with 512 threads two (waves 0..3 and 4..7 of a workgroup each cover the four SIMDs).  mode 0: every wave issues MFMAs;
+// 1: every wave issues VALU FMAs; 2 (512 threads): waves 0..3 issue MFMAs, waves 4..7 VALU FMAs, so each SIMD hosts one of each.
+// f16 != 0 uses v_mfma_f32_32x32x16_f16.
+__global__ void __launch_bounds__(512) k_mix(float* sink, int iters, int mode, int f16) {
+    // modes: 0 all waves MFMA; 1 all waves scalar v_fma_f32; 2 waves 0..3 MFMA + waves 4..7 scalar FMA; 3 all waves v_pk_fma_f32;
+    // 4 waves 0..3 MFMA + waves 4..7 packed FMA.  (This file is built with -fno-slp-vectorize: the scalar loop stays scalar.)
+    const bool do_mfma = mode == 0 || ((mode == 2 || mode == 4) && threadIdx.x < 256);
+    const bool packed = mode >= 3;
+    float s = 0.f;
+    if (do_mfma) {
+        f32x16 acc[2];
+        for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        if (f16) {
+            half8 a, b;
+            for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.25f + (float)((threadIdx.x + i) & 63) * 1e-3f); b[i] = (_Float16)(0.125f + (float)((threadIdx.x + 3 * i) & 31) * 2e-3f); }
+            for (int it = 0; it < 2 * iters; ++it) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+            }
+        } else {
+            float a = 0.25f + (float)(threadIdx.x & 63) * 1e-3f, b = 0.125f + (float)(threadIdx.x & 31) * 2e-3f;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < 16; ++i) s += acc[t][i];
+    } else if (!packed) {
+        float x[8];
+        for (int i = 0; i < 8; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
+        const float m = 0.999f, c = 1e-4f;
+        for (int it = 0; it < iters; ++it) {   // 8 independent chains x 4 = 32 v_fma_f32 per iteration
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i], m, c);
+        }
+        for (int i = 0; i < 8; ++i) s += x[i];
+    } else {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v x[4];
+        for (int i = 0; i < 4; ++i) x[i] = f2v{(float)(threadIdx.x + i) * 1e-3f, (float)(threadIdx.x + i + 4) * 1e-3f};
+        const f2v m = {0.999f, 0.999f}, c = {1e-4f, 1e-4f};
+        for (int it = 0; it < iters; ++it) {   // the same 32 FMAs as 16 v_pk_fma_f32
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_fma(x[i], m, c);
+        }
+        for (int i = 0; i < 4; ++i) s += x[i].x + x[i].y;
+    }
+    if (s == 12345.678f) sink[blockIdx.x] = s;
+}
+extern "C" int gdb_peak_mix(float* sink, int blocks, int threads, int iters, int mode, int f16, void* stream) {
+    hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, sink, iters, mode, f16);
+    return (int)hipGetLastError();
+}
