@@ -27,6 +27,7 @@
 int gdb_fail(int code, const char* fmt, ...);
 int gdb_check_cfg(const GdbConfig* c);
 int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs);
+int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st);
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1635,7 +1636,7 @@ static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t
 }
 
 template <int PREC>
-static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, int sched, hipStream_t st) {
+static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const void* ws, int sched, hipStream_t st) {
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * stage_v<PREC>();
     const size_t lds_max = 160 * 1024;
@@ -1661,6 +1662,12 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     // 283 vs 397 us f32; c2, S_max 3, 80 % busy: 67 vs 59 us f16, 139 vs 133 us f32 — the slot waves stay for S_max <= 3)
     const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && S > 3);
     if (want_dense && solo_lds <= lds_max) {
+        // gdb_prepare builds the plan when AUTO takes this schedule; for an explicit request on other shapes it is built here,
+        // into the plan region of the caller's workspace (a launch of its own on the same stream)
+        if (!(cfg->is_adaptive && S > 3)) {
+            int rc = gdb_build_dense_plan(cfg, fr, const_cast<void*>(ws), st);
+            if (rc) return rc;
+        }
         a.alias = 0;
         a.ntiles = fr->B * a.nrows * a.f.planMW;
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
@@ -1727,7 +1734,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.skip = env_skip; a.dbg = g_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream_;
-    return precision == GDB_PREC_F32 ? render_launch<GDB_PREC_F32>(a, cfg, fr, schedule, st) : render_launch<GDB_PREC_F16>(a, cfg, fr, schedule, st);
+    return precision == GDB_PREC_F32 ? render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, st) : render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,

@@ -341,6 +341,22 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
 
 static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, void* ws, size_t ws_bytes, void* stream_);
 
+// The dense plan alone (for a render call that asks for GDB_SCHED_DENSE on a frame whose prepare did not build it).
+__global__ void __launch_bounds__(256) k_plan(PrepArgs a) {
+    const int rowid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
+}
+int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st) {
+    WsLayout L = ws_layout(*cfg, *f);
+    PrepArgs a{};
+    a.B = f->B; a.H = f->H; a.W = f->W; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
+    a.near_far = f->d_near_far; a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
+    a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
+    hipLaunchKernelGGL(k_plan, dim3((f->B * f->H + 3) / 4), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_plan");
+    return GDB_OK;
+}
+
 extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
     return prepare_common(cfg, f, nullptr, ws, ws_bytes, stream_);
 }
@@ -377,7 +393,9 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     // the dense schedule's plan needs the depth prior; a frame prepared without it (build_rays / sample only) has none
     a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
-    a.nplan = f->d_depth_range ? (f->B * f->H + 3) / 4 : 0;
+    // Built here (inside this launch, ~1 us) when GDB_SCHED_AUTO will take the dense schedule; an explicit GDB_SCHED_DENSE on
+    // other shapes has gdb_render_bundles_* build it on demand (gdb_build_dense_plan, a launch of its own).
+    a.nplan = (f->d_depth_range && cfg->is_adaptive && cfg->max_num_samples > 3) ? (f->B * f->H + 3) / 4 : 0;
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;

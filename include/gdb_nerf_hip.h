@@ -99,7 +99,8 @@ int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7
  * bundle-map row (B*H rows) out[1] int32 values [n_windows, first bundle of window 0 .. n_windows-1, W]; a window is the run of
  * consecutive bundles whose first sample offset inside the row (exclusive prefix of the per-bundle sample counts,
  * bundle_sampler.py:179-189) falls into [out[2] * w, out[2] * (w + 1)) — at most 32 samples.  out[0] = byte offset of the
- * first row record.  Built only when the frame handed to gdb_prepare carries d_depth_range. */
+ * first row record.  Built by gdb_prepare when the frame carries d_depth_range and the config is adaptive with S_max > 3, else by
+ * the first render call that asks for GDB_SCHED_DENSE. */
 int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[3]);
 
 /* ---- MLP weights -------------------------------------------------------------------- */
@@ -202,7 +203,9 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
  *   (bundle_sampler.py:182-189): one wave per <= 32 consecutive samples of a bundle-map row, composite across lanes
- *   (uses the per-row plan gdb_prepare builds from d_depth_range).
+ *   (uses the per-row plan gdb_prepare builds from d_depth_range when GDB_SCHED_AUTO will take this schedule — adaptive
+ *   counts with S_max > 3; an explicit GDB_SCHED_DENSE on other shapes builds the plan itself, into the plan region of
+ *   d_workspace — the one place a render call writes the workspace).
  * Both are per-call arguments: the library keeps no process-global state (two engines with different settings may
  * interleave calls on different streams or threads).
  * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */

@@ -444,7 +444,8 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
     bundles covering the row, each holding at most 32 samples, and window w starts at the first bundle whose sample offset
     (exclusive prefix of the oracle's per-bundle counts) reaches L * w."""
     frame = synthetic.make_frame(Ho, Wo, V=2, B=B, scene=scene, seed=17)
-    eng = engine_for(frame, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=1), (3, 0), max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    eng.render()   # an explicit dense render builds the plan where prepare did not (fixed counts, S_max <= 3)
     H, W = Ho // 2, Wo // 2
     rays = oracle_rays(frame)
     smp = oracle.sample_bundles(rays, frame["depth_range"], frame["vol_range"], frame["near_far"][:, 0], frame["near_far"][:, 1], 2, S, 64,
