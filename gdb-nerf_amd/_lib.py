@@ -61,6 +61,10 @@ _SIGNATURES = {
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gdb_render_bundles_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gdb_merge": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "gdb_decoder_packed_floats": (C.c_int, [_CFG, C.c_int32, C.POINTER(C.c_size_t)]),
+    "gdb_pack_decoder_weights": (C.c_int, [_CFG, C.c_int32, C.POINTER(_P), _P]),
+    "gdb_decoder_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
+    "gdb_decode": (C.c_int, [_CFG, _FRM, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -21,14 +21,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgdbnerf_hip.so")
 PEAKS_SRC = os.path.join(HERE, "..", "tools", "ubench", "peaks.hip")
 PEAKS_LIB = os.path.join(HERE, "libgdbpeaks.so")
-SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip", "gdb_merge.hip")
+SOURCES = ("gdb_ops.hip", "gdb_mlp.hip", "gdb_fused.hip", "gdb_costvol.hip", "gdb_merge.hip", "gdb_decoder.hip")
 # -fno-slp-vectorize: packed f32 VALU (v_pk_*_f32) beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md,
 # "price of one filler beside MFMAs": +22..26 cycles per packed op) and hipcc's SLP pass packs adjacent f32 mul/add
 # under plain -O3; DESIGN.md §4.1 has the history of the stale-lane corruption first seen with it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # The operator mirrors keep a*b+c as two roundings (as separate torch ops are) unless written fmaf();
 # the fused fast path lets the compiler contract.
-CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off"}
+CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off", "gdb_decoder.hip": "off"}
 
 
 # Kernels whose private segment may only hold register spills — never data.  The round-1 "packed f32" corruption was a

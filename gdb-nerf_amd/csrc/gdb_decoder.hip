@@ -1,0 +1,382 @@
+// Next row N1: the residual-dense decoder that turns the 27 non-RGB bundle channels into the full-resolution
+// colour residual — `Decoder.forward`, networks/gdb_nerf/decoder_rdn.py:44-81 of the reference (in_conv, 3 ResidualDenseBlocks
+// with squeeze-excitation `:24-41`, `:7-21`, up-conv + PixelShuffle, 1x1 out_conv), called at network.py:51,170-175 — as HIP
+// kernels for gfx950.
+//
+// * Layout: channel-last.  The fused hot path already writes bundle rows (N_b, Q) = (H, W, channels), so the decoder reads its
+//   27 input channels straight out of `bundle_feat` (no permute / slice copy), and the dense block's torch.cat([x, x1, x2]) is
+//   one (N_b, 128) buffer [x 64 | x1 32 | x2 32] whose later convolutions simply read more channels: no concatenation copies.
+// * 3x3 convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, the reference's precision):
+//   output channels on the MFMA rows (32 per tile), 32 consecutive pixels of an image row on the columns (= lanes), K = (tap,
+//   input channel).  The unit of work is ONE wave = one image-row segment of 32 pixels x one tile of 32 output channels (one
+//   accumulator): a workgroup's 4 waves are 4 rows (32-channel layers) or 2 rows x 2 output tiles (64-channel layers) of the
+//   same 32-pixel column, so that a 256x320 map gives 2560 / 5120 waves for the 1024 SIMDs (the first version's 8-row
+//   workgroups gave 320 workgroups for 256 CUs: a quarter of the CUs did double duty, 1.6 ms).  Per
+//   32-channel chunk of the input the workgroup stages its rows + halo in LDS (pixel stride 34 floats: the 8-byte B-operand
+//   reads of a wave are bank-conflict-free) and every wave runs 9 taps x 16 K-steps of MFMAs on it.  Weights are packed on the
+//   host in operand order (one float2 per lane per two K-steps, per output tile) and stream from L2.
+// * The up stage is folded on the host: PixelShuffle is a permutation and there is no non-linearity between the 64 -> 256 up
+//   convolution and the 1x1 out_conv, so out_conv o PixelShuffle o up = ONE 3x3 convolution 64 -> 12 (4 sub-pixels x 3 colours;
+//   products summed in fp64, rounded once): 21x fewer flops for that stage, same function up to fp32 rounding.
+// * Squeeze-excitation: deterministic two-stage channel mean (per-block partial sums, reduced in a fixed order), the two tiny
+//   linears + sigmoid in one workgroup per batch item, and one element-wise pass x += x3 * gate (+ the global residual at the end).
+#include "gdb_internal.h"
+#include <cstring>
+#include <vector>
+
+int gdb_fail(int code, const char* fmt, ...);
+int gdb_check_cfg(const GdbConfig* c);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float F2 __attribute__((ext_vector_type(2)));
+typedef float F4 __attribute__((ext_vector_type(4)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define DEC_NF 64    // num_feats (network.py:51)
+#define DEC_G 32     // growth rate (decoder_rdn.py:27)
+#define DEC_CS 128   // channel stride of the dense-block buffer [x | x1 | x2]
+#define DEC_PX 34    // pixels per staged row: 32 + halo
+#define DEC_CHS 34   // floats per staged pixel: 32 channels of the chunk + 2 (bank spread for the 8-byte reads)
+#define DEC_SE_R 4   // SE bottleneck: 64 / 16
+#define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
+
+static inline int acc_row_h(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- packed weights -------------------------------------------------------------------------------------------------
+// A convolution layer: [tile NT][chunk][tap 9][u 8][lane 64][2] floats; element e of lane (i, h) = W[32 tile + i][32 chunk + 4 u +
+// 2 h + e][tap], zero beyond the layer's channels.  (K-step 2u + e pairs the input channels 4u + e (half 0) and 4u + 2 + e
+// (half 1): a lane's two K-steps are two CONSECUTIVE channels, one 8-byte LDS read.)
+static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 9 * 8 * 64 * 2 * nt; }
+struct DecLayout {
+    size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b, total;
+};
+static DecLayout dec_layout(int nlayers) {
+    DecLayout L{};
+    size_t o = 0;
+    L.in_w = o; o += conv_floats(27, 2);
+    L.in_b = o; o += 64;
+    for (int b = 0; b < nlayers; ++b) {
+        L.blk[b][0] = o; o += conv_floats(64, 1);
+        L.blk[b][1] = o; o += conv_floats(96, 1);
+        L.blk[b][2] = o; o += conv_floats(128, 2);
+        L.blk[b][3] = o; o += DEC_SE_R * DEC_NF;
+        L.blk[b][4] = o; o += DEC_NF * DEC_SE_R;
+    }
+    L.up_w = o; o += conv_floats(64, 1);
+    L.up_b = o; o += 32;
+    L.total = (o + 63) / 64 * 64;
+    return L;
+}
+// w: (cout, cin, 3, 3) row-major as torch stores it
+static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
+    const int nchunk = (cin + 31) / 32;
+    for (int t = 0; t < nt; ++t)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int u = 0; u < 8; ++u)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 2; ++e) {
+                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 4 * u + 2 * h + e;
+                            float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                            out[(((((size_t)t * nchunk + ch) * 9 + tap) * 8 + u) * 64 + l) * 2 + e] = v;
+                        }
+}
+
+static int dec_check(const GdbConfig* cfg, int nlayers) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "the HIP decoder is built for bundle_size 2 (one up stage); got %d", cfg->bundle_size);
+    if (nlayers < 1 || nlayers > 3) return gdb_fail(GDB_E_BADARG, "decoder layers %d outside 1..3", nlayers);
+    return GDB_OK;
+}
+
+extern "C" int gdb_decoder_packed_floats(const GdbConfig* cfg, int32_t num_layers, size_t* out_floats) {
+    int rc = dec_check(cfg, num_layers); if (rc) return rc;
+    if (!out_floats) return gdb_fail(GDB_E_BADARG, "out_floats is NULL");
+    *out_floats = dec_layout(num_layers).total;
+    return GDB_OK;
+}
+
+// h_tensors in state-dict order (decoder_rdn.py:55-65): in_conv.weight (64,27,3,3), in_conv.bias, then per block conv1.weight
+// (32,64,3,3), conv2.weight (32,96,3,3), conv3.weight (64,128,3,3), se.fc.0.weight (4,64), se.fc.2.weight (64,4), then
+// up.0.weight (256,64,3,3), up.0.bias (256), out_conv.weight (3,64,1,1), out_conv.bias (3): 2 + 5 num_layers + 4 pointers.
+extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers, const float* const* t, float* out) {
+    int rc = dec_check(cfg, num_layers); if (rc) return rc;
+    if (!t || !out) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    const int n = 2 + 5 * num_layers + 4;
+    for (int i = 0; i < n; ++i)
+        if (!t[i]) return gdb_fail(GDB_E_BADARG, "decoder tensor %d is NULL", i);
+    const DecLayout L = dec_layout(num_layers);
+    memset(out, 0, sizeof(float) * L.total);
+    const int cin0 = GDB_CFR + GDB_CV;  // 27
+    pack_conv(t[0], DEC_NF, cin0, 2, out + L.in_w);
+    memcpy(out + L.in_b, t[1], sizeof(float) * DEC_NF);
+    for (int b = 0; b < num_layers; ++b) {
+        const float* const* q = t + 2 + 5 * b;
+        pack_conv(q[0], DEC_G, DEC_NF, 1, out + L.blk[b][0]);
+        pack_conv(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blk[b][1]);
+        pack_conv(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blk[b][2]);
+        memcpy(out + L.blk[b][3], q[3], sizeof(float) * DEC_SE_R * DEC_NF);
+        memcpy(out + L.blk[b][4], q[4], sizeof(float) * DEC_NF * DEC_SE_R);
+    }
+    // fold: out_conv o PixelShuffle(2) o up.  PixelShuffle: up channel 4 k + s (s = dy*2 + dx) -> feature k of sub-pixel s.
+    // folded output channel c = 3 s + o:  W[c][ci][tap] = sum_k Wout[o][k] Wup[4k + s][ci][tap],  b[c] = sum_k Wout[o][k] bup[4k + s] + bout[o]
+    const float* wup = t[n - 4]; const float* bup = t[n - 3]; const float* wout = t[n - 2]; const float* bout = t[n - 1];
+    std::vector<float> wf((size_t)12 * DEC_NF * 9);
+    for (int s = 0; s < 4; ++s)
+        for (int o = 0; o < 3; ++o) {
+            for (int ci = 0; ci < DEC_NF; ++ci)
+                for (int tap = 0; tap < 9; ++tap) {
+                    double acc = 0;
+                    for (int k = 0; k < DEC_NF; ++k) acc += (double)wout[o * DEC_NF + k] * (double)wup[((size_t)(4 * k + s) * DEC_NF + ci) * 9 + tap];
+                    wf[((size_t)(3 * s + o) * DEC_NF + ci) * 9 + tap] = (float)acc;
+                }
+            double acc = bout[o];
+            for (int k = 0; k < DEC_NF; ++k) acc += (double)wout[o * DEC_NF + k] * (double)bup[4 * k + s];
+            out[L.up_b + 3 * s + o] = (float)acc;
+        }
+    pack_conv(wf.data(), 12, DEC_NF, 1, out + L.up_w);
+    return GDB_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------------------------
+struct DecWs { size_t X, S, T, part, gate, total; int nblk; };
+static DecWs dec_ws(int B, int H, int W) {
+    DecWs w{};
+    const size_t n = (size_t)B * H * W;
+    w.nblk = (int)(((size_t)H * W + DEC_RED - 1) / DEC_RED);  // pixels per partial-sum block
+    size_t o = 0;
+    w.X = o; o = align_up(o + sizeof(float) * n * DEC_CS, 256);
+    w.S = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256);
+    w.T = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256);
+    w.part = o; o = align_up(o + sizeof(float) * (size_t)B * w.nblk * DEC_NF, 256);
+    w.gate = o; o = align_up(o + sizeof(float) * (size_t)B * DEC_NF, 256);
+    w.total = o;
+    return w;
+}
+extern "C" int gdb_decoder_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    if (!shape || !out_bytes) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (shape->B < 1 || shape->H < 1 || shape->W < 1) return gdb_fail(GDB_E_SHAPE, "non-positive bundle map");
+    *out_bytes = dec_ws(shape->B, shape->H, shape->W).total;
+    return GDB_OK;
+}
+
+// ---- 3x3 convolution ----------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in; int in_stride, in_off, cin, nchunk, vec;  // vec: the input rows allow 16-byte loads
+    const float* w; const float* bias;
+    float* out; int out_stride, out_off, cout, relu;
+    float* out2; int out2_stride;   // optional second copy of the output (channels 0..cout-1)
+    float* rgb;                     // folded up stage: (B,3,2H,2W) NCHW, channel c = 3 s + o of sub-pixel s = dy*2 + dx
+    int B, H, W, tilesX, tilesY;
+};
+
+extern __shared__ float dsmem[];
+
+// NT = output tiles of the layer (1: 32 channels, 4 rows per workgroup; 2: 64 channels, 2 rows x 2 tiles per workgroup).
+template <int NT>
+__global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
+    constexpr int TR = 4 / NT;   // rows per workgroup
+    float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int t = wid % NT, wrow = wid / NT;   // this wave's output tile and row of the workgroup
+    const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
+    const int x0 = bx * 32, y0 = by * TR;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+        acc[r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+    const size_t img = (size_t)b * a.H * a.W;
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+        __syncthreads();  // the previous chunk's reads are done
+        // stage the rows + halo of this 32-channel chunk: zero outside the image (padding = 1) and beyond the layer's channels
+        for (int idx = tid; idx < (TR + 2) * DEC_PX * 8; idx += 256) {
+            const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+            const int px = x0 - 1 + rx, py = y0 - 1 + ry, ci = 32 * ch + 4 * g;
+            F4 v = {0.f, 0.f, 0.f, 0.f};
+            if (px >= 0 && px < a.W && py >= 0 && py < a.H) {
+                const float* src = a.in + (img + (size_t)py * a.W + px) * a.in_stride + a.in_off + ci;
+                if (a.vec && ci + 3 < a.cin) v = *(const F4*)src;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (ci + k < a.cin) v[k] = src[k];
+                }
+            }
+            F2* dst = (F2*)(lds + (size_t)p * DEC_CHS + 4 * g);  // 8-byte aligned (DEC_CHS is even)
+            dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
+        }
+        __syncthreads();
+        const float* wch = a.w + ((size_t)t * a.nchunk + ch) * 9 * 8 * 64 * 2 + (size_t)lane * 2;
+        const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            F2 w[8];  // this tap's 16 K-steps
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = *(const F2*)(wch + (size_t)(tap * 8 + u) * 128);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const F2 bv = *(const F2*)(brow + (size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * u);
+                acc = MFMA32(w[u][0], bv[0], acc);
+                acc = MFMA32(w[u][1], bv[1], acc);
+            }
+        }
+    }
+    // epilogue: lane (j, h) holds output channels 32 t + 8 g + 4 h + (0..3) of pixel (y, x0 + j)
+    const int x = x0 + j, y = y0 + wrow;
+    if (x >= a.W || y >= a.H) return;
+    const size_t pix = img + (size_t)y * a.W + x;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = 32 * t + 8 * g + 4 * h;
+        if (co >= a.cout) continue;
+        F4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
+            const int Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = co + k;
+                if (c < 12) {
+                    const int s = c / 3, o = c - 3 * s;
+                    a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (s >> 1)) * Wo + 2 * x + (s & 1)] = v[k];
+                }
+            }
+        } else {
+            *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;   // all buffers: strides and offsets multiples of 4
+            if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
+        }
+    }
+}
+
+// ---- squeeze-excitation ------------------------------------------------------------------------------------------------
+// partial[b][blk][c] = sum over the block's DEC_RED pixels of T[.][c]; fixed order inside a block (16 pixel lanes per float4 of
+// channels, each in pixel order, then a fixed tree over the lanes), fixed order over blocks in k_se_gate: bit-reproducible.
+__global__ void __launch_bounds__(256) k_chan_partial(const float* __restrict__ T, int HW, int nblk, float* __restrict__ part) {
+    __shared__ F4 red[256];
+    const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int p0 = blk * DEC_RED, p1 = min(HW, p0 + DEC_RED);
+    F4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + pl; p < p1; p += 16) s = s + *(const F4*)(T + ((size_t)b * HW + p) * DEC_NF + 4 * c4);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 8; st >= 1; st >>= 1) {
+        if (pl < st) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 16 * st];
+        __syncthreads();
+    }
+    if (pl == 0) *(F4*)(part + ((size_t)b * nblk + blk) * DEC_NF + 4 * c4) = red[c4];
+}
+// gate[b][c] = sigmoid(W2 relu(W1 mean))   decoder_rdn.py:17-21.  1024 threads: 16 groups x 64 channels sum the partials
+// (group g takes blocks g, g + 16, ...), then a fixed tree over the groups.
+__global__ void __launch_bounds__(1024) k_se_gate(const float* __restrict__ part, int nblk, float inv_hw, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, float* __restrict__ gate) {
+    __shared__ float red[1024];
+    __shared__ float mean[DEC_NF], hid[DEC_SE_R];
+    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int k = g; k < nblk; k += 16) s += part[((size_t)b * nblk + k) * DEC_NF + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 8; st >= 1; st >>= 1) {
+        if (g < st) red[threadIdx.x] += red[threadIdx.x + 64 * st];
+        __syncthreads();
+    }
+    if (g == 0) mean[c] = red[c] * inv_hw;
+    __syncthreads();
+    if (threadIdx.x < DEC_SE_R) {
+        float acc = 0.f;
+        for (int k = 0; k < DEC_NF; ++k) acc += w1[threadIdx.x * DEC_NF + k] * mean[k];
+        hid[threadIdx.x] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (g == 0) {
+        float acc = 0.f;
+        for (int r = 0; r < DEC_SE_R; ++r) acc += w2[c * DEC_SE_R + r] * hid[r];
+        gate[(size_t)b * DEC_NF + c] = 1.f / (1.f + expf(-acc));
+    }
+}
+// x <- x + x3 * gate  (decoder_rdn.py:40), and on the last block + shallow (the decoder's global residual, :78)
+__global__ void __launch_bounds__(256) k_se_apply(float* __restrict__ X, const float* __restrict__ T, const float* __restrict__ gate,
+                                                  const float* __restrict__ S, size_t n, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of 16 per pixel
+    if (i >= n * 16) return;
+    const size_t p = i >> 4; const int c = (int)(i & 15) * 4;
+    const int b = (int)(p / (size_t)HW);
+    const F4 t = *(const F4*)(T + p * DEC_NF + c), g = *(const F4*)(gate + (size_t)b * DEC_NF + c);
+    F4 x = *(const F4*)(X + p * DEC_CS + c);
+    x = x + t * g;
+    if (S) x = x + *(const F4*)(S + p * DEC_NF + c);
+    *(F4*)(X + p * DEC_CS + c) = x;
+}
+
+// ---- entry ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(4 / NT + 2) * DEC_PX * DEC_CHS;
+    hipLaunchKernelGGL((k_conv3x3<NT>), dim3((unsigned)(a.B * a.tilesX * a.tilesY)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, int32_t ld_bundle_feat,
+                          const float* d_packed, int32_t num_layers, void* d_ws, size_t ws_bytes, float* d_rgb_c, void* stream_) {
+    int rc = dec_check(cfg, num_layers); if (rc) return rc;
+    if (!shape || !d_bundle_feat || !d_packed || !d_ws || !d_rgb_c) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    const int B = shape->B, H = shape->H, W = shape->W;
+    if (B < 1 || H < 1 || W < 1) return gdb_fail(GDB_E_SHAPE, "non-positive bundle map");
+    const int Q = 3 * cfg->bundle_size * cfg->bundle_size + GDB_CFR + GDB_CV, n_rgb = 3 * cfg->bundle_size * cfg->bundle_size;
+    if (ld_bundle_feat < Q) return gdb_fail(GDB_E_SHAPE, "bundle_feat row stride %d < %d channels", ld_bundle_feat, Q);
+    const DecWs ws = dec_ws(B, H, W);
+    if (ws_bytes < ws.total) return gdb_fail(GDB_E_WORKSPACE, "decoder workspace %zu B < required %zu B", ws_bytes, ws.total);
+    if ((size_t)B * H * W * DEC_CS >= ((size_t)1 << 40)) return gdb_fail(GDB_E_SHAPE, "frame too large");
+    const DecLayout L = dec_layout(num_layers);
+    hipStream_t st = (hipStream_t)stream_;
+    float* X = (float*)((char*)d_ws + ws.X); float* S = (float*)((char*)d_ws + ws.S); float* T = (float*)((char*)d_ws + ws.T);
+    float* part = (float*)((char*)d_ws + ws.part); float* gate = (float*)((char*)d_ws + ws.gate);
+    auto conv = [&](ConvArgs a, int nt) -> hipError_t {
+        a.B = B; a.H = H; a.W = W; a.tilesX = (W + 31) / 32;
+        a.nchunk = (a.cin + 31) / 32;
+        a.vec = (a.in_stride % 4 == 0) && (a.in_off % 4 == 0) && (a.cin % 4 == 0) && ((uintptr_t)a.in % 16 == 0);
+        a.tilesY = (H + 4 / nt - 1) / (4 / nt);
+        return nt == 2 ? launch_conv<2>(a, st) : launch_conv<1>(a, st);
+    };
+    hipError_t e;
+#define CK(x) do { e = (x); if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "decoder launch: %s", hipGetErrorString(e)); } while (0)
+    {   // shallow = in_conv(bundle channels n_rgb..Q-1)   decoder_rdn.py:76; written as block 0's x and kept for the global residual
+        ConvArgs a{};
+        a.in = d_bundle_feat; a.in_stride = ld_bundle_feat; a.in_off = n_rgb; a.cin = Q - n_rgb;
+        a.w = d_packed + L.in_w; a.bias = d_packed + L.in_b;
+        a.out = X; a.out_stride = DEC_CS; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.out2 = S; a.out2_stride = DEC_NF;
+        CK(conv(a, 2));
+    }
+    const size_t n = (size_t)B * H * W;
+    for (int b = 0; b < num_layers; ++b) {   // ResidualDenseBlock.forward   decoder_rdn.py:35-41
+        ConvArgs a{};
+        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.out = X; a.out_stride = DEC_CS; a.relu = 1;
+        a.cin = DEC_NF; a.w = d_packed + L.blk[b][0]; a.out_off = DEC_NF; a.cout = DEC_G;
+        CK(conv(a, 1));
+        a.cin = DEC_NF + DEC_G; a.w = d_packed + L.blk[b][1]; a.out_off = DEC_NF + DEC_G;
+        CK(conv(a, 1));
+        a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + L.blk[b][2]; a.out = T; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
+        CK(conv(a, 2));
+        hipLaunchKernelGGL(k_chan_partial, dim3((unsigned)(B * ws.nblk)), dim3(256), 0, st, T, H * W, ws.nblk, part);
+        CK(hipGetLastError());
+        hipLaunchKernelGGL(k_se_gate, dim3((unsigned)B), dim3(1024), 0, st, part, ws.nblk, 1.f / (float)((size_t)H * W), d_packed + L.blk[b][3],
+                           d_packed + L.blk[b][4], gate);
+        CK(hipGetLastError());
+        hipLaunchKernelGGL(k_se_apply, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st, X, T, gate,
+                           b == num_layers - 1 ? S : (const float*)nullptr, n, H * W);
+        CK(hipGetLastError());
+    }
+    {   // out_conv(PixelShuffle(up(x))) as one folded 64 -> 12 convolution   decoder_rdn.py:79-80
+        ConvArgs a{};
+        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.cin = DEC_NF; a.w = d_packed + L.up_w; a.bias = d_packed + L.up_b;
+        a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
+        CK(conv(a, 1));
+    }
+#undef CK
+    return GDB_OK;
+}

@@ -194,6 +194,51 @@ class HotPathEngine:
                                       int(bool(reweighting)), img.data_ptr(), p(outs[0]), p(outs[1]), self._stream()))
         return img, outs[0], outs[1]
 
+    # ---- next row N1: the decoder -----------------------------------------------------------------
+    def load_decoder_weights(self, state: Dict[str, "torch.Tensor | np.ndarray"], num_layers: int, prefix: str = "") -> None:
+        """Pack the Decoder's tensors (keys `<prefix>in_conv.weight` ... as in decoder_rdn.py:55-65) and upload them once."""
+        keys = ["in_conv.weight", "in_conv.bias"]
+        for i in range(num_layers):
+            keys += [f"blocks.{i}.conv1.weight", f"blocks.{i}.conv2.weight", f"blocks.{i}.conv3.weight", f"blocks.{i}.se.fc.0.weight", f"blocks.{i}.se.fc.2.weight"]
+        keys += ["up.0.weight", "up.0.bias", "out_conv.weight", "out_conv.bias"]
+        cin = self.cfg.feat_dim + 3 + self.cfg.voxel_dim
+        expect = {"in_conv.weight": (64, cin, 3, 3), "up.0.weight": (256, 64, 3, 3), "out_conv.weight": (3, 64, 1, 1)}
+        arrs, ptrs = [], (C.c_void_p * len(keys))()
+        for i, k in enumerate(keys):
+            v = state[prefix + k]
+            a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+            if k in expect and tuple(a.shape) != expect[k]:
+                raise ValueError(f"{prefix + k} has shape {tuple(a.shape)}, expected {expect[k]}")
+            arrs.append(a)
+            ptrs[i] = a.ctypes.data
+        n = C.c_size_t()
+        _lib.check(self.lib.gdb_decoder_packed_floats(C.byref(self.cfg), int(num_layers), C.byref(n)))
+        host = np.zeros(n.value, dtype=np.float32)
+        _lib.check(self.lib.gdb_pack_decoder_weights(C.byref(self.cfg), int(num_layers), ptrs, host.ctypes.data))
+        self.dec_weights, self.dec_layers = torch.from_numpy(host).to(self.device), int(num_layers)
+
+    @_on_device
+    def decode(self, bundle_feat: torch.Tensor) -> torch.Tensor:
+        """Decoder.forward (decoder_rdn.py:67-81) on the frame last prepared: bundle_feat (n_bundles, Q) or the packed
+        (n_bundles, Q + 2) render, read in place (channels 3b^2 .. Q-1 are the decoder's input, network.py:170-174) ->
+        rgb_c (B, 3, Ho, Wo)."""
+        if getattr(self, "dec_weights", None) is None:
+            raise ValueError("load_decoder_weights() first")
+        f = self._need_frame()
+        nb = self.n_bundles
+        if bundle_feat.dim() != 2 or bundle_feat.shape[0] != nb or bundle_feat.shape[1] < self.Q:
+            raise ValueError(f"bundle_feat has shape {tuple(bundle_feat.shape)}, expected ({nb}, >= {self.Q})")
+        _chk(bundle_feat, "bundle_feat")
+        need = C.c_size_t()
+        _lib.check(self.lib.gdb_decoder_workspace_bytes(C.byref(self.cfg), C.byref(f), C.byref(need)))
+        if getattr(self, "_dec_ws", None) is None or self._dec_ws.numel() < need.value:
+            self._dec_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        b = self.cfg.bundle_size
+        rgb_c = torch.empty((f.B, 3, f.H * b, f.W * b), device=self.device)
+        _lib.check(self.lib.gdb_decode(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), int(bundle_feat.shape[1]), self.dec_weights.data_ptr(),
+                                       self.dec_layers, self._dec_ws.data_ptr(), self._dec_ws.numel(), rgb_c.data_ptr(), self._stream()))
+        return rgb_c
+
     def set_schedule(self, mode: int) -> None:
         """Work decomposition of THIS engine's fused calls (a per-call argument of the C ABI, no process-wide state):
         0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment, 3 dense (one wave per <= 32 consecutive samples

@@ -49,6 +49,9 @@ class Network(nn.Module):
         self.upsampler = Decoder(feat_dim + 3 + self.voxel_dim, 3, num_feats=64, num_layers=self.dec_layers, upscale_factor=self.b_size)
         self.reweighting = nrf.reweighting
         self.hot_path = getattr(nrf, "hot_path", "fused")  # "fused" | "mirrors"
+        # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
+        # False keeps the PyTorch-ROCm module.  bundle_size 2 only (one up stage).
+        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2
         self._feat_dim = feat_dim
         self._engine = None
 
@@ -60,6 +63,11 @@ class Network(nn.Module):
                                          max_mipmap_level=self.max_mipmap_level, feat_dim=self._feat_dim, voxel_dim=self.voxel_dim,
                                          hid_dim=self.nerf_hidden_dims, viewdir_agg=self.viewdir_agg, device=device)
         self.nerf.sync_engine(self._engine)
+        if self.hip_decoder:
+            v = tuple(p._version for p in self.upsampler.parameters())
+            if getattr(self._engine, "_dec_versions", None) != v:
+                self._engine.load_decoder_weights({k: t.detach() for k, t in self.upsampler.state_dict().items()}, self.dec_layers)
+                self._engine._dec_versions = v
         return self._engine
 
     def render_bundles(self, rgbs_feat_rgb_dir, vox_feat, z_vals, indices, samples_per_bundle):
@@ -124,7 +132,10 @@ class Network(nn.Module):
 
         nerf_feat = bundle_feat.view(B, H, W, -1).permute(0, 3, 1, 2)
         n_rgb = 3 * b * b
-        rgb_c = self.upsampler(nerf_feat[:, n_rgb:])
+        if eng is not None and self.hip_decoder:
+            rgb_c = eng.decode(bundle_feat)   # reads channels n_rgb.. of the bundle rows in place
+        else:
+            rgb_c = self.upsampler(nerf_feat[:, n_rgb:])
         if eng is not None:  # N1: pixel-shuffle + add (+ re-weighting) + the two x b upsamplings in one HIP kernel
             img, nerf_depth, opacity = eng.merge(bundle_feat, rgb_c.contiguous().float(), bundle_depth, bundle_opacity, self.reweighting)
             return {"rgb": img, "nerf_depth": nerf_depth, "mvs_depth": mvs_depth, "opacity": opacity}, mvs_depths, blend_rgbs

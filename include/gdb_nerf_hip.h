@@ -252,6 +252,28 @@ int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle
               const float* d_bundle_depth, const float* d_bundle_opacity, int32_t reweighting, float* d_img,
               float* d_out_depth, float* d_out_opacity, void* stream);
 
+/* ---- the decoder itself (next row N1) --------------------------------------------------- */
+/* Decoder.forward, networks/gdb_nerf/decoder_rdn.py:44-81 (instantiated at network.py:51 as Decoder(C_f+3+C_v, 3, num_feats=64,
+ * num_layers=nerf.dec_layers, upscale_factor=b); called at network.py:170-175): in_conv, num_layers ResidualDenseBlocks with
+ * squeeze-excitation, up-conv + PixelShuffle, 1x1 out_conv — 3x3 convolutions as implicit GEMMs on fp32 MFMA, channel-last.
+ * bundle_size 2 only (one up stage).
+ *
+ * gdb_pack_decoder_weights: h_tensors in state-dict order — in_conv.weight (64,C_in,3,3), in_conv.bias, then per block
+ * conv1.weight (32,64,3,3), conv2.weight (32,96,3,3), conv3.weight (64,128,3,3), se.fc.0.weight (4,64), se.fc.2.weight (64,4),
+ * then up.0.weight (256,64,3,3), up.0.bias, out_conv.weight (3,64,1,1), out_conv.bias: 2 + 5 num_layers + 4 host pointers.
+ * The up stage is folded into one 64 -> 12 convolution on the host (no non-linearity sits between up-conv, PixelShuffle and
+ * out_conv). */
+int gdb_decoder_packed_floats(const GdbConfig* cfg, int32_t num_layers, size_t* out_floats);
+int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers, const float* const* h_tensors, float* h_out);
+/* shape needs B, H, W (the bundle map). */
+int gdb_decoder_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes);
+/* d_bundle_feat: the hot path's output rows (B*H*W, ld_bundle_feat >= Q), read in place: the decoder's input is channels
+ * 3b² .. Q-1 of every row (network.py:170-174: nerf_feat[:, 3b²:]).  d_rgb_c (B,3,H*b,W*b) = the reference's `rgb_c`; feed it
+ * to gdb_merge.  d_workspace: gdb_decoder_workspace_bytes, caller-owned scratch. */
+int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, int32_t ld_bundle_feat,
+               const float* d_packed_decoder_weights, int32_t num_layers, void* d_workspace, size_t workspace_bytes,
+               float* d_rgb_c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,125 @@
+"""Next row N1: the RDN decoder on the HIP library (gdb_decoder.hip) against the reference's own Decoder
+(networks/gdb_nerf/decoder_rdn.py:44-81): the fixture F7 holds the reference module's weights, an input and its output."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, max_abs
+from gdb_nerf_amd import _lib, synthetic
+from gdb_nerf_amd.engine import HotPathEngine
+from gdb_nerf_amd.networks.gdb_nerf.decoder_rdn import Decoder
+
+KEYS = lambda n: (["in_conv.weight", "in_conv.bias"] + [f"blocks.{i}.{k}" for i in range(n) for k in (
+    "conv1.weight", "conv2.weight", "conv3.weight", "se.fc.0.weight", "se.fc.2.weight")] + ["up.0.weight", "up.0.bias", "out_conv.weight", "out_conv.bias"])
+
+
+def _dec_state(f7):
+    return {k[len("sd.upsampler."):]: np.asarray(v, dtype=np.float32) for k, v in f7.items() if k.startswith("sd.upsampler.")}  # (the fixture stores exactly-representable tensors as float16)
+
+
+def _unpack_conv(packed, cout, cin, nt):
+    """Inverse of pack_conv (gdb_decoder.hip): [tile][chunk][tap][u][lane][e] -> (cout, cin, 3, 3)."""
+    nchunk = (cin + 31) // 32
+    a = packed[:nt * nchunk * 9 * 8 * 64 * 2].reshape(nt, nchunk, 9, 8, 64, 2)
+    w = np.zeros((cout, cin, 9), np.float32)
+    for t in range(nt):
+        for ch in range(nchunk):
+            for u in range(8):
+                for l in range(64):
+                    i, h = l & 31, l >> 5
+                    for e in range(2):
+                        co, ci = 32 * t + i, 32 * ch + 4 * u + 2 * h + e
+                        if co < cout and ci < cin:
+                            w[co, ci, :] = a[t, ch, :, u, l, e]
+    return w.reshape(cout, cin, 3, 3)
+
+
+def test_packed_decoder_weights_and_the_folded_up_stage():
+    """Host logic, no GPU: the operand-order packing is a permutation of the reference's tensors, and the folded 64 -> 12
+    convolution (out_conv o PixelShuffle o up-conv, summed in fp64) reproduces the reference's three modules."""
+    from gdb_nerf_amd import build
+    build.build()
+    lib = _lib.load()
+    f7 = load_golden("F7_network")
+    sd = _dec_state(f7)
+    cfg = _lib.GdbConfig(2, 3, 1, 0, 64, 3, 16, 8, 64, 1)
+    n = C.c_size_t()
+    assert lib.gdb_decoder_packed_floats(C.byref(cfg), 3, C.byref(n)) == 0
+    arrs = [np.ascontiguousarray(sd[k], dtype=np.float32) for k in KEYS(3)]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    host = np.full(n.value, np.nan, np.float32)
+    assert lib.gdb_pack_decoder_weights(C.byref(cfg), 3, ptrs, host.ctypes.data) == 0
+    assert np.isfinite(host).all()
+    conv_floats = lambda cin, nt: ((cin + 31) // 32) * 9 * 8 * 64 * 2 * nt
+    o = 0
+    assert np.array_equal(_unpack_conv(host[o:], 64, 27, 2), sd["in_conv.weight"]); o += conv_floats(27, 2)
+    assert np.array_equal(host[o:o + 64], sd["in_conv.bias"]); o += 64
+    for i in range(3):
+        assert np.array_equal(_unpack_conv(host[o:], 32, 64, 1), sd[f"blocks.{i}.conv1.weight"]); o += conv_floats(64, 1)
+        assert np.array_equal(_unpack_conv(host[o:], 32, 96, 1), sd[f"blocks.{i}.conv2.weight"]); o += conv_floats(96, 1)
+        assert np.array_equal(_unpack_conv(host[o:], 64, 128, 2), sd[f"blocks.{i}.conv3.weight"]); o += conv_floats(128, 2)
+        assert np.array_equal(host[o:o + 256].reshape(4, 64), sd[f"blocks.{i}.se.fc.0.weight"]); o += 256
+        assert np.array_equal(host[o:o + 256].reshape(64, 4), sd[f"blocks.{i}.se.fc.2.weight"]); o += 256
+    wf = torch.from_numpy(_unpack_conv(host[o:], 12, 64, 1)); o += conv_floats(64, 1)
+    bf = torch.from_numpy(host[o:o + 12].copy())
+    x = torch.randn(2, 64, 9, 11, generator=torch.Generator().manual_seed(0))
+    want = F.conv2d(F.pixel_shuffle(F.conv2d(x, torch.from_numpy(sd["up.0.weight"]), torch.from_numpy(sd["up.0.bias"]), padding=1), 2),
+                    torch.from_numpy(sd["out_conv.weight"]), torch.from_numpy(sd["out_conv.bias"]))
+    y = F.conv2d(x, wf, bf, padding=1)                                # (2, 12, 9, 11), channel 3 s + o, s = dy*2 + dx
+    got = y.view(2, 2, 2, 3, 9, 11).permute(0, 3, 4, 1, 5, 2).reshape(2, 3, 18, 22)
+    assert max_abs(got.numpy(), want.numpy()) <= 2e-6 * float(want.abs().max())
+    with pytest.raises(ValueError, match="bundle_size 2"):
+        _lib.check(lib.gdb_decoder_packed_floats(C.byref(_lib.GdbConfig(4, 3, 1, 0, 64, 3, 16, 8, 64, 1)), 3, C.byref(n)))
+
+
+def _engine(B, H, W, sd, layers=3):
+    frame = synthetic.make_frame(2 * H, 2 * W, V=2, B=B, seed=1)
+    eng = HotPathEngine()
+    eng.prepare({k: torch.from_numpy(v).cuda() for k, v in frame.items()})
+    eng.load_decoder_weights(sd, layers)
+    return eng
+
+
+@pytest.mark.gpu
+def test_hip_decoder_matches_the_reference_fixture():
+    f7 = load_golden("F7_network")
+    sd = _dec_state(f7)
+    x = f7["dec_in"]                                                     # (1, 27, 32, 48)
+    _, _, H, W = x.shape
+    eng = _engine(1, H, W, sd)
+    for ld in (39, 41):                                                  # the three-tensor and the packed render layouts
+        bf = torch.zeros((H * W, ld))
+        bf[:, 12:39] = torch.from_numpy(x[0]).permute(1, 2, 0).reshape(H * W, 27)
+        bf[:, :12] = 7.0                                                 # the fine-RGB channels (and depth / opacity) are not the decoder's
+        got = eng.decode(bf.cuda().contiguous())
+        e = max_abs(got.cpu().numpy(), f7["dec_out"])
+        print(f"HIP decoder vs the reference's Decoder (F7, ld {ld}): max abs err {e:.3e} on values up to {np.abs(f7['dec_out']).max():.2f}")
+        assert e <= 2e-5 * max(1.0, float(np.abs(f7["dec_out"]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,layers", [(1, 32, 48, 3), (2, 19, 45, 3), (1, 7, 33, 2), (1, 256, 320, 3), (1, 130, 70, 1)])
+def test_hip_decoder_matches_torch_module(B, H, W, layers):
+    """Ragged bundle maps (edges inside a 32-pixel tile and inside a row group), batch 2, 1..3 blocks, and the DTU-eval size
+    (two rows per wave), against the PyTorch module on the same GPU."""
+    torch.manual_seed(3)
+    dec = Decoder(27, 3, num_feats=64, num_layers=layers, upscale_factor=2).cuda().eval()
+    with torch.no_grad():
+        for p in dec.parameters():                                        # biases and gates that matter
+            p.mul_(1.5)
+    eng = _engine(B, H, W, {k: v.detach() for k, v in dec.state_dict().items()}, layers)
+    x = torch.randn(B, 27, H, W, device="cuda")
+    bf = torch.zeros((B * H * W, 39), device="cuda")
+    bf[:, 12:] = x.permute(0, 2, 3, 1).reshape(B * H * W, 27)
+    with torch.no_grad():
+        want = dec(x)
+    got = eng.decode(bf)
+    e, scale = max_abs(got.cpu().numpy(), want.cpu().numpy()), float(want.abs().max())
+    print(f"HIP decoder vs torch ({B},{H},{W}) x{layers}: max abs err {e:.3e}, output scale {scale:.2f}")
+    assert e <= 3e-5 * max(1.0, scale)
+    assert torch.equal(got, eng.decode(bf))                               # deterministic (two-stage channel means, no atomics)
+    with pytest.raises(ValueError, match="bundle_feat"):
+        eng.decode(bf[:-1])
