@@ -124,8 +124,14 @@ __global__ void __launch_bounds__(256) k_costvol(CostVolArgs a) {
         for (int v = 0; v < VT; ++v) {
             {
                 const float* pl = a.feat + (((size_t)b * a.V + v) * a.C + c) * plane;
+#ifndef GDB_XP_CV_SCALAR   // one 8-byte load per x pair (any 4-byte alignment costs the same 16 TA cycles per wave instruction:
+                           // tools/ubench/ta_rate.hip); two dword loads per pair measured slower: 115 vs 72 us at the 256x320 stage
                 F2c t0 = *(const F2c*)(pl + off0[v]), t1 = *(const F2c*)(pl + off1[v]);
                 val[v] = t0.x * w00[v] + t0.y * w01[v] + t1.x * w10[v] + t1.y * w11[v];      // :472
+#else
+                const float a0 = pl[off0[v]], a1 = pl[off0[v] + 1], b0 = pl[off1[v]], b1 = pl[off1[v] + 1];
+                val[v] = a0 * w00[v] + a1 * w01[v] + b0 * w10[v] + b1 * w11[v];              // :472
+#endif
                 mean += val[v];
             }
         }

@@ -27,7 +27,9 @@ for tag, (C, D, sf, sv, inv) in {"stage0 (C32, D64, 64x80 from 128x160 maps, dis
     if inv:
         dv = dn.get_depth_values(nf, D, True).expand(-1, -1, Ht, Wt).contiguous()
     else:
-        mid = 500 + 300 * torch.rand(1, 1, Ht, Wt, device="cuda")
+        # the last stage sweeps around the previous stage's (upsampled, hence smooth) depth: a low-pass depth prior, as
+        # synthetic.make_frame builds it — white noise here would measure an incoherent gather no frame produces
+        mid = t(fr["depth_range"]).mean(1, keepdim=True)
         dv = dn.get_depth_values(torch.cat((mid - 20, mid + 25), 1), D, False)
     E, Et = t(fr["src_exts"]), t(fr["tar_ext"])
     hip = timeit(lambda: costvol.build_feature_volume(feat, E, Ks, Et, Kt, dv, inv))
