@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
+    ap.add_argument("--frame-ring", type=int, default=0,
+                    help="number of distinct device copies of the input frame the steps cycle through (0 = as many as it takes to "
+                         "exceed the 256 MiB Infinity Cache, at most 8): consecutive steps then read their inputs from HBM, not from cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary-precision record, PSNR, measured peaks and t_frame")
     ap.add_argument("--streams", type=int, default=1,
@@ -270,6 +273,17 @@ def main():
 
     frame_np = synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=0)  # rows mode: every rank holds the same frame
     frame = to_dev(frame_np, dev)
+    # The steps cycle through a ring of distinct device copies of the frame whose total size exceeds the 256 MiB Infinity Cache
+    # (c2: 52.8 MB of inputs per frame -> 7 copies), so that a step's inputs come from HBM as they would in an evaluation sweep;
+    # with one resident frame the whole working set would sit in L2 / Infinity Cache and the HBM fraction be cache-side.
+    in_bytes = sum(v.numel() * v.element_size() for v in frame.values())
+    nring = args.frame_ring if args.frame_ring > 0 else max(1, min(8, -(-(320 << 20) // in_bytes)))
+    ring = [frame] + [{k: v.clone() for k, v in frame.items()} for _ in range(nring - 1)]
+    ring_i = [0]
+
+    def next_frame():
+        ring_i[0] = (ring_i[0] + 1) % len(ring)
+        return ring[ring_i[0]]
     timed = Timed(dist, dev, rehearse)
     kern_pairs, ag_pairs = [], []
 
@@ -294,14 +308,14 @@ def main():
             e, o, st = lanes[counter[0] % len(lanes)]
             counter[0] += 1
             with torch.cuda.stream(st):
-                e.prepare(frame)
+                e.prepare(next_frame())
                 if sample:
                     e0, e1 = events(); e0.record()
                 e.render(0, H, precision, o)
                 if sample:
                     e1.record(); pairs.append((e0, e1))
             return
-        eng.prepare(frame)
+        eng.prepare(next_frame())
         if args.path == "fused":
             if sample:
                 e0, e1 = events(); e0.record()
@@ -325,7 +339,7 @@ def main():
         r0, r1 = gather.strip
 
     def step_rows(sample):
-        eng.prepare(frame)
+        eng.prepare(next_frame())
         if sample:
             e0, e1 = events(); e0.record()
         eng.render_packed(r0, r1, None, gather.full)
@@ -358,6 +372,7 @@ def main():
         rows_ok = bool(torch.equal(gather.full, eng.render_packed(0, H)))
         # frames mode: every rank its own frame (seeded by rank)
         frame = to_dev(synthetic.make_frame(Ho, Wo, V=V, scene=wl["scene"], seed=rank), dev)
+        ring[:] = [frame] + [{k: v.clone() for k, v in frame.items()} for _ in range(nring - 1)]
         dt_frames = timed.run(step_frame, args.warmup, args.steps)
         kern_frames = ev_ms(kern_pairs)
         rec_rows = {"mode": "rows: one frame, row strips, packed output, one all-gather", "scaling": "strong",
@@ -423,7 +438,8 @@ def main():
         "vs_baseline": None, "dtype": DTYPE[pname], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
                    "path": args.path, "precision": pname, "schedule": args.schedule, "shard": args.shard if world > 1 else "none",
-                   "prewarm_ms": args.prewarm_ms, "streams": args.streams},
+                   "prewarm_ms": args.prewarm_ms, "streams": args.streams,
+                   "frame_ring": nring, "input_MB_per_frame": round(in_bytes / 1e6, 1)},
         "t_hot_ms": ms_per_step, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
         "roofline": roof,
     }

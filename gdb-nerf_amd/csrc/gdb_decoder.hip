@@ -64,7 +64,7 @@ static DecLayout dec_layout(int nlayers) {
     }
     L.up_w = o; o += conv_floats(64, 1);
     L.up_b = o; o += 32;
-    L.total = (o + 63) / 64 * 64;
+    L.total = (o + 8 * 128 + 63) / 64 * 64;  // + one tap block: the conv kernel's weight prefetch runs one tap ahead
     return L;
 }
 // w: (cout, cin, 3, 3) row-major as torch stores it
@@ -190,33 +190,60 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
         acc[r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
     const size_t img = (size_t)b * a.H * a.W;
+    // staging plan of this thread: the (pixel, 4-channel group) slots it fills are the same for every chunk, so their source
+    // offsets and LDS addresses are computed once (the divisions by 34 are not cheap, and VALU cycles are matrix cycles on the
+    // fp32 datapath)
+    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
+    int soff[NSLOT];   // float offset of the slot's source inside the input (row stride included), -1: outside the image / no slot
+    int loff[NSLOT];   // float offset of the slot in LDS
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int idx = tid + 256 * s;
+        const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
+        const bool slot = idx < (TR + 2) * DEC_PX * 8;
+        loff[s] = slot ? p * DEC_CHS + 4 * g : -1;
+        soff[s] = (slot && px >= 0 && px < a.W && py >= 0 && py < a.H) ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off + 4 * g) : -1;
+    }
+    const float* inb = a.in + img * a.in_stride;   // (a frame's input is < 2^31 floats: checked on the host)
+    const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2 + (size_t)lane * 2;
+    const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
+    // weights: the next tap's 8 packets are loaded while the current tap's 16 MFMAs run (L2 latency under the matrix pipe)
+    F2 wn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wn[u] = *(const F2*)(wbase + (size_t)u * 128);
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();  // the previous chunk's reads are done
         // stage the rows + halo of this 32-channel chunk: zero outside the image (padding = 1) and beyond the layer's channels
-        for (int idx = tid; idx < (TR + 2) * DEC_PX * 8; idx += 256) {
-            const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
-            const int px = x0 - 1 + rx, py = y0 - 1 + ry, ci = 32 * ch + 4 * g;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (loff[s] < 0) continue;
+            const int ci = 32 * ch + 4 * (tid & 7);  // the slot's 4-channel group: (tid + 256 s) & 7 = tid & 7
             F4 v = {0.f, 0.f, 0.f, 0.f};
-            if (px >= 0 && px < a.W && py >= 0 && py < a.H) {
-                const float* src = a.in + (img + (size_t)py * a.W + px) * a.in_stride + a.in_off + ci;
+            if (soff[s] >= 0) {
+                const float* src = inb + soff[s] + 32 * ch;
                 if (a.vec && ci + 3 < a.cin) v = *(const F4*)src;
                 else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) if (ci + k < a.cin) v[k] = src[k];
                 }
             }
-            F2* dst = (F2*)(lds + (size_t)p * DEC_CHS + 4 * g);  // 8-byte aligned (DEC_CHS is even)
+            F2* dst = (F2*)(lds + loff[s]);  // 8-byte aligned (DEC_CHS is even)
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
-        const float* wch = a.w + ((size_t)t * a.nchunk + ch) * 9 * 8 * 64 * 2 + (size_t)lane * 2;
-        const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
-            F2 w[8];  // this tap's 16 K-steps
+            F2 w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = *(const F2*)(wch + (size_t)(tap * 8 + u) * 128);
+            for (int u = 0; u < 8; ++u) w[u] = wn[u];
+            {   // prefetch: next tap of this chunk, or tap 0 of the next chunk (the last prefetch of the layer reads the packed
+                // buffer's next layer / tail padding: in bounds by construction of dec_layout, never used)
+                const float* wnext = wbase + ((size_t)ch * 9 + tap + 1) * 8 * 128;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wn[u] = *(const F2*)(wnext + (size_t)u * 128);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const F2 bv = *(const F2*)(brow + (size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * u);
@@ -331,7 +358,8 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     if (ld_bundle_feat < Q) return gdb_fail(GDB_E_SHAPE, "bundle_feat row stride %d < %d channels", ld_bundle_feat, Q);
     const DecWs ws = dec_ws(B, H, W);
     if (ws_bytes < ws.total) return gdb_fail(GDB_E_WORKSPACE, "decoder workspace %zu B < required %zu B", ws_bytes, ws.total);
-    if ((size_t)B * H * W * DEC_CS >= ((size_t)1 << 40)) return gdb_fail(GDB_E_SHAPE, "frame too large");
+    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_CS ? ld_bundle_feat : DEC_CS) >= ((size_t)1 << 31))
+        return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging offsets");
     const DecLayout L = dec_layout(num_layers);
     hipStream_t st = (hipStream_t)stream_;
     float* X = (float*)((char*)d_ws + ws.X); float* S = (float*)((char*)d_ws + ws.S); float* T = (float*)((char*)d_ws + ws.T);
