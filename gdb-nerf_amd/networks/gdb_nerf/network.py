@@ -49,6 +49,8 @@ class Network(nn.Module):
         self.upsampler = Decoder(feat_dim + 3 + self.voxel_dim, 3, num_feats=64, num_layers=self.dec_layers, upscale_factor=self.b_size)
         self.reweighting = nrf.reweighting
         self.hot_path = getattr(nrf, "hot_path", "fused")  # "fused" | "mirrors"
+        # arithmetic of the NeRF MLP in the fused kernel: "f32" (fp32 MFMA, the reference's precision; default) | "f16" (f16 operands)
+        self.precision = {"f32": 1, "f16": 0}[str(getattr(nrf, "precision", "f32"))]
         # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
         # False keeps the PyTorch-ROCm module.  bundle_size 2 only (one up stage).
         self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2
@@ -62,6 +64,7 @@ class Network(nn.Module):
                                          inv_depth=self.inv_depth, global_num_depth=self.global_num_depth,
                                          max_mipmap_level=self.max_mipmap_level, feat_dim=self._feat_dim, voxel_dim=self.voxel_dim,
                                          hid_dim=self.nerf_hidden_dims, viewdir_agg=self.viewdir_agg, device=device)
+        self._engine.precision = self.precision
         self.nerf.sync_engine(self._engine)
         if self.hip_decoder:
             v = tuple(p._version for p in self.upsampler.parameters())

@@ -95,17 +95,17 @@ def _batch(f7, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hot_path,tol", [("mirrors", 5e-4), ("fused", 2e-3)])
-def test_network_forward_matches_reference(f7, hot_path, tol):
-    """Whole Network.forward on the MI355X (CNNs on PyTorch-ROCm, hot path on the HIP library) against
-    the reference's CPU forward with the same checkpoint."""
-    net = _net(f7, **{"nerf.hot_path": hot_path}).cuda()
+@pytest.mark.parametrize("hot_path,precision,tol", [("mirrors", "f32", 5e-4), ("fused", "f32", 5e-4), ("fused", "f16", 2e-3)])
+def test_network_forward_matches_reference(f7, hot_path, precision, tol):
+    """Whole Network.forward on the MI355X (CNNs on PyTorch-ROCm; hot path, cost volume, decoder and merge on the HIP library)
+    against the reference's CPU forward with the same checkpoint."""
+    net = _net(f7, **{"nerf.hot_path": hot_path, "nerf.precision": precision}).cuda()
     with torch.no_grad():
         ret, mvs_depths, blend = net(_batch(f7, "cuda"))
     assert blend == [] and len(mvs_depths) == 2
     assert tuple(ret["rgb"].shape) == (1, 3, 64, 96) and tuple(ret["nerf_depth"].shape) == (1, 64, 96)
     e = max_abs(ret["rgb"].cpu().numpy(), f7["rgb"])
-    print(f"network forward ({hot_path}): max |rgb - reference| = {e:.3e}")
+    print(f"network forward ({hot_path}, {precision}): max |rgb - reference| = {e:.3e}")
     assert e <= tol
     assert max_abs(ret["mvs_depth"].cpu().numpy(), f7["mvs_depth"]) <= 1e-3 * float(np.abs(f7["mvs_depth"]).max())
     assert max_abs(ret["nerf_depth"].cpu().numpy(), f7["nerf_depth"]) <= 2e-3 * float(np.abs(f7["nerf_depth"]).max())
@@ -173,3 +173,29 @@ def test_evaluator_depth_metrics():
     assert 0.0 < ev.depth["acc_2"][0] < ev.depth["acc_10"][0] <= 1.0
     res = ev.summarize()                   # prints the depth rows, returns the image metrics, clears the accumulators
     assert set(res) == {"psnr", "ssim"} and not ev.depth
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("yaml,scene", [("configs/dtu_eval.yaml", "dtu"), ("configs/dtu_pretrain.yaml", "dtu"), ("configs/llff_eval.yaml", "llff"),
+                                        ("configs/nerf_eval.yaml", "nerf")])
+def test_every_config_runs_fused_and_agrees_with_the_operator_chain(yaml, scene):
+    """All four YAMLs of the reference (S_max 3 / 6, adaptive or not, re-weighting on / off): the production forward (fused kernel on
+    the schedule GDB_SCHED_AUTO picks — the dense one for nerf_eval's S_max 6 adaptive —, HIP cost volume, HIP decoder, merge) against
+    the same network run through the exact-fp32 operator mirrors and the PyTorch decoder, random initialisation."""
+    from gdb_nerf_amd import synthetic
+    fr = synthetic.make_frame(64, 96, V=3, scene=scene, seed=11)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
+             "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
+    outs = {}
+    for name, opts in {"fused": [], "mirrors": ["nerf.hot_path", "mirrors", "nerf.hip_decoder", "False"]}.items():
+        torch.manual_seed(5)
+        net = make_network(make_cfg(yaml, opts)).eval().cuda()
+        with torch.no_grad():
+            outs[name] = net(batch)[0]
+    for k in ("rgb", "nerf_depth", "opacity", "mvs_depth"):
+        a, b = outs["fused"][k].cpu().numpy(), outs["mirrors"][k].cpu().numpy()
+        assert np.isfinite(a).all() and a.shape == b.shape
+        scale = max(1.0, float(np.abs(b).max()))
+        print(f"{yaml} {k}: fused vs operator chain max abs diff {max_abs(a, b):.3e} (scale {scale:.1f})")
+        assert max_abs(a, b) <= 1e-3 * scale
