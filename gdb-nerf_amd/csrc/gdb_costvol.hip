@@ -156,9 +156,11 @@ extern "C" int gdb_build_feature_volume(const float* d_src_feat, const float* d_
     hipLaunchKernelGGL(k_costvol_proj, dim3((B * V + 63) / 64), dim3(64), 0, st, B, V, d_src_exts, d_src_ints, d_tar_exts, d_tar_ints, d_proj_ws);
     LAUNCH_CHECK("k_costvol_proj");
     // channels per thread: all of them (splitting channels over more threads measured no faster on MI355X:
-    // 44 / 118 us at the two DTU stage shapes for cpt = 32, 8, 4); GDB_COSTVOL_CPT overrides for experiments
+    // 44 / 118 us at the two DTU stage shapes for cpt = 32, 8, 4); GDB_COSTVOL_CPT overrides in the diagnostic build
     int cpt = C;
+#ifdef GDB_DIAG  // diagnostic build only: the product entry reads no environment
     if (getenv("GDB_COSTVOL_CPT")) cpt = atoi(getenv("GDB_COSTVOL_CPT")) > 0 ? atoi(getenv("GDB_COSTVOL_CPT")) : C;
+#endif
     const int tiles = (Ht * Wt + 255) / 256, groups = (C + cpt - 1) / cpt;
     if ((size_t)B * tiles * D * groups >= ((size_t)1 << 31)) return gdb_fail(GDB_E_SHAPE, "cost volume too large for the launch grid");
     const int nblk = B * tiles * D * groups;

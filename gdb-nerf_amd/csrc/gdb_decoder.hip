@@ -40,8 +40,6 @@ typedef float F4 __attribute__((ext_vector_type(4)));
 #define DEC_SE_R 4   // SE bottleneck: 64 / 16
 #define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
-static inline int acc_row_h(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 // ---- packed weights -------------------------------------------------------------------------------------------------
 // A convolution layer: [tile NT][chunk][tap 9][u 8][lane 64][2] floats; element e of lane (i, h) = W[32 tile + i][32 chunk + 4 u +
 // 2 h + e][tap], zero beyond the layer's channels.  (K-step 2u + e pairs the input channels 4u + e (half 0) and 4u + 2 + e

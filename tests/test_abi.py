@@ -152,3 +152,22 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert f"{len(names)} entry points" in r.stdout
+
+
+def test_product_library_reads_no_environment():
+    """no global mutable state and no hidden knobs in the product entry points — every getenv in the HIP
+    sources sits inside an `#ifdef GDB_DIAG` block (the diagnostic build of tools/)."""
+    csrc = os.path.join(ROOT, "gdb-nerf_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        depth = []  # stack of booleans: is this #if level a GDB_DIAG block
+        for ln, line in enumerate(open(os.path.join(csrc, fn), encoding="utf-8"), 1):
+            st = line.strip()
+            if st.startswith(("#ifdef", "#ifndef", "#if ")):
+                depth.append(st.startswith("#ifdef GDB_DIAG"))
+            elif st.startswith("#endif") and depth:
+                depth.pop()
+            elif "getenv(" in st and not st.startswith("//"):
+                assert any(depth), f"{fn}:{ln}: getenv outside the diagnostic build"
+        assert not re.search(r"^static\s+(int|unsigned|float|bool)\s+g_\w+", open(os.path.join(csrc, fn)).read(), flags=re.M), fn
