@@ -152,7 +152,16 @@ def cpu_baseline(wl, frame, weights):
                 gdb_oracle.hot_path(frame, weights, max_num_samples=wl["S"], is_adaptive=wl["adaptive"])
                 t.append(time.perf_counter() - t0)
         rows.append({"threads": threads, "value": Ho * Wo / float(np.mean(t[1:])), "s_per_frame": float(np.mean(t[1:]))})
-    return {"value": rows[0]["value"], "unit": "rays/s", "cores": ncpu, "kind": "port", "cpu_model": model, "rows": rows,
+    # c1 (64x80, the reference's own CPU-runnable case) is always reported beside the benched workload
+    c1 = WORKLOADS["c1"]
+    f1, w1 = synthetic.make_frame(c1["Ho"], c1["Wo"], V=c1["V"], scene=c1["scene"], seed=0), weights
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gdb_oracle.hot_path(f1, w1, max_num_samples=c1["S"], is_adaptive=c1["adaptive"])
+        t.append(time.perf_counter() - t0)
+    c1_row = {"workload": "c1 64x80", "threads": ncpu, "value": c1["Ho"] * c1["Wo"] / float(np.mean(t[1:])), "s_per_frame": float(np.mean(t[1:]))}
+    return {"value": rows[0]["value"], "unit": "rays/s", "cores": ncpu, "kind": "port", "cpu_model": model, "rows": rows, "c1": c1_row,
             "sample": f"3 full frames of {Ho}x{Wo} per row through the numpy float32 oracle (first dropped, mean of 2); BLAS matmuls "
                       f"threaded to the row's thread count, element-wise numpy on one thread"}
 

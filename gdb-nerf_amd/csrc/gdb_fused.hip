@@ -250,8 +250,12 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 #define PHASE_FENCE() asm volatile("" ::: "memory")
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #ifdef GDB_DEBUG_STAMPS   // diagnostic build only: per-wave s_memtime stamps (tools/stamps.py)
-#define STAMP(i) do { if (dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    if (lane == 0) ((unsigned long long*)dbg)[(size_t)(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (i)] = t_; } } while (0)
+// slot i: s_memtime (shader-clock ticks, a per-CU counter); stamps 0 and 9 also leave s_memrealtime (100 MHz, chip-wide) in slots
+// 10 and 11: launch span and the clock the wave really ran at (MI355X guide, DVFS give-back item 6)
+#define STAMP(i) do { if (dbg) { unsigned long long t_, r_ = 0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if ((i) == 0 || (i) == 9) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) :: "memory"); \
+    if (lane == 0) { unsigned long long* d_ = (unsigned long long*)dbg + (size_t)(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16; d_[(i)] = t_; \
+        if ((i) == 0) d_[10] = r_; if ((i) == 9) d_[11] = r_; } } } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif

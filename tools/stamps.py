@@ -20,9 +20,14 @@ lib = _lib.load(); lib.gdb_debug_set_buffer.argtypes = [ctypes.c_void_p]; lib.gd
 nblk = 16384
 dbg = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device="cuda")
 lib.gdb_debug_set_buffer(dbg.data_ptr())
-eng.render(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); eng.render(); e1.record(); torch.cuda.synchronize()
+launch_us = e0.elapsed_time(e1) * 1e3
 lib.gdb_debug_set_buffer(None)
-t = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :10].reshape(-1, 10).astype(np.int64)
+raw12 = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :12].astype(np.int64).reshape(-1, 12)
+raw12 = raw12[(raw12[:, 0] > 0) & (raw12[:, 9] > 0)]
+raw = raw12[:, :10]
+t = raw.reshape(-1, 10)
 if sched != 3:
     t[:, 1] = t[:, 0]
 t = t[(t[:, 0] > 0) & (t[:, 9] > 0)]
@@ -33,4 +38,9 @@ tot = (full[:, 9] - full[:, 0]).mean()
 print(f"{len(full)} active waves; mean lifetime {tot:.0f} cycles (s_memtime ticks)")
 for n, m in zip(names, d.mean(0)):
     print(f"  {n:22s} {m:9.0f}  {100 * m / tot:5.1f} %")
-print("kernel span (first start -> last end):", (t[:, 9].max() - t[:, 0].min()), "ticks")
+rt0, rt1 = raw12[:, 10], raw12[:, 11]                      # s_memrealtime at wave start / end, 100 MHz, chip-wide
+span_us = (rt1.max() - rt0.min()) / 100.0
+clk = np.median((raw12[:, 9] - raw12[:, 0]) / np.maximum(rt1 - rt0, 1) * 0.1)   # GHz
+busy = ((rt1 - rt0).sum() / 100.0) / span_us / 1024        # average waves resident per SIMD
+print(f"launch: first wave start -> last wave end {span_us:.1f} us ({launch_us:.1f} us between events); shader clock while the waves ran "
+      f"{clk:.2f} GHz (median, stamped build); {busy:.2f} waves resident per SIMD on average")
