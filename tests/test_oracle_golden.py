@@ -215,3 +215,33 @@ def test_texture_mip_matches_grid_sample_witness(H, W, V, C):
     vi, ni = np.meshgrid(np.arange(V), np.arange(N), indexing="ij")
     want = stack[l0, vi, ni] * (1 - fr) + stack[l1, vi, ni] * fr
     assert max_abs(got, want) <= 5e-6   # values up to ~4: a few fp32 ulps between two orders of the same lerps
+
+
+def test_volrend_restatements_match_a_padded_cumprod_witness():
+    """Independent witness for the two un-pinned nerfacc ops (utils.py:35,110).  nerfacc.volrend.render_weight_from_alpha is
+    w_i = alpha_i * prod_{j < i, same ray}(1 - alpha_j) and accumulate_along_rays is index_add_(weights * values); the reference's
+    own commented pure-torch variant (utils.py:46-85) spells the first as a padded per-ray cumprod.  Here the same structure is
+    built with torch (scatter into a (rays, max_samples + 1) table, cumprod along it — WITHOUT the comment's +1e-6, which the live
+    code does not have) and compared with the oracle's sequential loop on ragged, sorted ray indices with empty rays."""
+    import torch
+    rng = np.random.default_rng(9)
+    counts = rng.integers(0, 7, size=300)                      # empty rays included
+    idx = np.repeat(np.arange(300), counts).astype(np.int64)
+    n = idx.shape[0]
+    alpha = rng.uniform(0, 1, n).astype(np.float32)
+    alpha[rng.random(n) < 0.05] = 1.0                            # opaque samples: everything behind gets weight 0
+    vals = rng.standard_normal((n, 5)).astype(np.float32)
+    got_w = oracle.weights_from_alpha(alpha, idx, 300)
+    # witness
+    a, ind = torch.from_numpy(alpha), torch.from_numpy(idx)
+    starts = torch.cat((torch.zeros(1, dtype=torch.long), torch.from_numpy(counts).cumsum(0)))[:-1]
+    pos = torch.arange(n) - starts[ind]
+    T = torch.ones((300, int(counts.max()) + 1))
+    T[ind, pos + 1] = 1.0 - a
+    T = torch.cumprod(T[:, :-1], dim=-1)
+    want_w = (a * T[ind, pos]).numpy()
+    assert max_abs(got_w, want_w) <= 1e-6
+    feat, depth, opac = oracle.accumulate(vals[:, :4], vals[:, 4], got_w, idx, 300)
+    acc = torch.zeros((300, 6)).index_add_(0, ind, torch.from_numpy(np.concatenate((vals, np.ones((n, 1), np.float32)), 1) * got_w[:, None]))
+    assert max_abs(feat, acc[:, :4].numpy()) <= 2e-6 and max_abs(depth, acc[:, 4].numpy()) <= 2e-6 and max_abs(opac, acc[:, 5].numpy()) <= 2e-6
+    assert np.all(opac[counts == 0] == 0) and np.all(feat[counts == 0] == 0)
