@@ -1,6 +1,6 @@
 """t_frame: whole Network.forward (CNNs on PyTorch-ROCm + hot path on the HIP library) at DTU eval 512x640, 3 source
 views, random-init weights, the reference's timing protocol (run.py:56-73: synchronise, wall clock, drop the first
-iteration, FPS = 1 / mean).  Prints a JSON object; hot_path in {fused, mirrors}, hip_cost_volume on/off."""
+iteration, FPS = 1 / mean).  Prints a JSON object; hot_path in {fused, mirrors}, precision, hip_cost_volume and hip_decoder on/off."""
 import json, os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from gdb_nerf_amd import synthetic
@@ -12,8 +12,11 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
          "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
 res = {}
-for name, opts in {"fused + hip cost volume": [], "fused, torch cost volume": ["mvs.hip_cost_volume", "False"],
-                   "operator mirrors + hip cost volume": ["nerf.hot_path", "mirrors"]}.items():
+for name, opts in {"fused (fp32 MFMA) + hip cost volume + hip decoder [default]": [],
+                   "fused + hip cost volume, torch decoder": ["nerf.hip_decoder", "False"],
+                   "fused f16 operands + hip cost volume + hip decoder": ["nerf.precision", "f16"],
+                   "fused, torch cost volume, torch decoder": ["mvs.hip_cost_volume", "False", "nerf.hip_decoder", "False"],
+                   "operator mirrors + hip cost volume, torch decoder": ["nerf.hot_path", "mirrors", "nerf.hip_decoder", "False"]}.items():
     torch.manual_seed(0)
     net = make_network(make_cfg("configs/dtu_eval.yaml", opts)).eval().cuda()
     times = []
