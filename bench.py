@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the GDB-NeRF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2] [--precision f32|f16] [--path fused|unfused]
+    python bench.py --gpus N --steps K --warmup W [--workload c2] [--precision f32|f16|f32x] [--path fused|unfused]
 
 One *step* = one pass of the hot path (per-frame preparation: camera block + feature mip pyramid; then
 build_rays → sample → encode → MLP → composite) over one synthetic frame of the workload, inputs already
@@ -52,9 +52,10 @@ WORKLOADS = {
 }
 # vendor peaks (MI355X_MICROARCH.md): HBM3E 8 TB/s; dense matrix 2.5 PFLOP/s f16/bf16, 157.3 TFLOP/s f32-input MFMA
 HBM_PEAK_GBS = 8000.0
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}
-DTYPE = {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate (fetch / geometry / composite f32)"}
-PREC = {"f16": 0, "f32": 1}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32x": 2500.0 / 3}  # f32x: three f16 MFMAs per algorithmic product
+DTYPE = {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate (fetch / geometry / composite f32)",
+         "f32x": "split-f16 MFMA operands (hi + lo pairs, 3 MFMAs per product, ~22-bit), f32 accumulate (fetch / geometry / composite f32)"}
+PREC = {"f16": 0, "f32": 1, "f32x": 2}
 
 
 def alg_bytes(Ho, Wo, V, b=2, Cf=16, Cv=8, D=8, levels=3):
@@ -228,7 +229,7 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run for this long before the W warm-up steps, so clocks have ramped (0 = off)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="arithmetic of the NeRF MLP in the fused kernel")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"], help="arithmetic of the NeRF MLP in the fused kernel")
     ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
@@ -460,16 +461,23 @@ def main():
         eng.prepare(frame)
         res["psnr_delta_db"] = psnr_delta_db(eng.render(0, H, prec)[0], ubf, H, W)
         res["max_abs_err_vs_fp32_chain"] = float((eng.render(0, H, prec)[0] - ubf).abs().max())
-        # the other precision, timed the same way on the same frame (shorter region)
-        other = "f16" if args.precision == "f32" else "f32"
-        pairs2 = []
+        # the other precisions, timed the same way on the same frame (shorter region): "secondary" = f16 operands (f32 when the
+        # headline is not f32), "secondary_f32x" = the split-f16 path
         k2 = max(20, min(args.steps, 1000))
-        dt2 = timed.run(lambda s: step_frame(s, PREC[other], pairs2), min(args.warmup, 100), k2)
-        km2 = ev_ms(pairs2)
-        res["secondary"] = {"dtype": DTYPE[other], "precision": other, "value": Ho * Wo * k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
-                            "steps": k2, "kernel_ms": km2, "hbm_frac": ab / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "mfma_frac": af / (km2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[other],
-                            "psnr_delta_db": psnr_delta_db(eng.render(0, H, PREC[other])[0], ubf, H, W)}
+
+        def time_other(other):
+            pairs2 = []
+            dt2 = timed.run(lambda s: step_frame(s, PREC[other], pairs2), min(args.warmup, 100), k2)
+            km2 = ev_ms(pairs2)
+            obf = eng.render(0, H, PREC[other])[0]
+            return {"dtype": DTYPE[other], "precision": other, "value": Ho * Wo * k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
+                    "steps": k2, "kernel_ms": km2, "hbm_frac": ab / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "mfma_frac": af / (km2 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[other],
+                    "psnr_delta_db": psnr_delta_db(obf, ubf, H, W), "max_abs_err_vs_fp32_chain": float((obf - ubf).abs().max())}
+        others = [p for p in ("f16", "f32", "f32x") if p != args.precision]
+        res["secondary"] = time_other(others[0])
+        if "f32x" in others[1:]:
+            res["secondary_f32x"] = time_other("f32x")
         del ubf
         # throughput of a sweep over independent frames with two frames in flight: frame i on HIP stream i % 2 (own engine,
         # workspace and outputs), so one frame's fill / drain overlaps its neighbour's steady state.  Reported beside the headline,
@@ -491,7 +499,7 @@ def main():
         try:
             pk = measure_peaks(dev)
             pk["hbm_frac_of_measured"] = hbm_gbs / pk["hbm_triad_GBps"]
-            pk["mfma_frac_of_measured"] = mfma_tf / pk[f"mfma_{pname}_TFLOPs"]
+            pk["mfma_frac_of_measured"] = mfma_tf / (pk["mfma_f16_TFLOPs"] / 3 if pname == "f32x" else pk[f"mfma_{pname}_TFLOPs"])
             res["peaks_measured"] = pk
         except Exception as ex:  # measurement extras never take the headline down
             res["peaks_measured"] = {"error": repr(ex)}

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
 ABI_VERSION = 2
-PREC_F16, PREC_F32 = 0, 1
+PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4

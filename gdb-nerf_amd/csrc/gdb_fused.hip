@@ -88,7 +88,14 @@ enum {  // fp32 tables in accumulator layout [h][16] (bias tables initialise a l
     F32SEC_FLOATS = (S32_BW2 + 1 + 63) / 64 * 64
 };
 
-size_t gdb_mfma_section_floats() { return (size_t)MFMA_FLOATS + F32SEC_FLOATS; }
+// ---- low halves of the f16 fragments (precision GDB_PREC_F32X), appended to the f32 section --------------------
+// The split-f16 path represents every MFMA operand as hi + lo with hi = f16(x), lo = f16(x - hi) (about 22 bits) and forms
+// a product as lo·hi + hi·lo + hi·hi on the f16 matrix pipe with fp32 accumulation.  Its hi weight fragments ARE the f16
+// section's fragments; this section holds the N_FRAGS matching lo fragments (same indices, same element order).  The fp32
+// tables (TB_FC, TD_AGG, TD_W2, scalars) of the f16 section are shared.
+enum { XLO_OFF = MFMA_FLOATS + F32SEC_FLOATS, XLO_FLOATS = N_FRAGS * 256 };
+
+size_t gdb_mfma_section_floats() { return (size_t)MFMA_FLOATS + F32SEC_FLOATS + XLO_FLOATS; }
 
 // Accumulator row of (register r, half h) in a 32x32 MFMA tile; also the k index that element
 // (r & 7) of k-step (r >> 3) carries when the tile is reused as a B operand.
@@ -98,18 +105,24 @@ namespace {
 struct Packer {
     const float* w;  // fp32 section
     float* out;      // MFMA section
+    float* lo = nullptr;  // low-half fragments (XLO section) or null
+    // element e of fragment idx: hi = f16(v) into the f16 section, lo = f16(v - hi) into the low-half section
+    void put(int idx, int e, float v) {
+        const _Float16 hi = (_Float16)v;
+        ((_Float16*)(out + (size_t)idx * 256))[e] = hi;
+        if (lo) ((_Float16*)(lo + (size_t)idx * 256))[e] = (_Float16)(v - (float)hi);
+    }
     // kmap(h, i) -> column of W (or -1 for a zero), rows r -> output feature rowmap(r) (or -1)
     // biasOff >= 0: element (bh, bi) of every row carries that row's bias (the B operand has 1.0 there)
     template <class RowMap, class KMap>
     void frag(int idx, int wOff, int ld, RowMap rowmap, KMap kmap, int biasOff = -1, int bh = 0, int bi = 0) {
-        _Float16* f = (_Float16*)(out + (size_t)idx * 256);
         for (int l = 0; l < 64; ++l) {
             int r = l & 31, h = l >> 5, orow = rowmap(r);
             for (int i = 0; i < 8; ++i) {
                 int col = kmap(h, i);
                 float v = (orow >= 0 && col >= 0) ? w[wOff + orow * ld + col] : 0.f;
                 if (biasOff >= 0 && h == bh && i == bi) v = orow >= 0 ? w[biasOff + orow] : 0.f;
-                f[l * 8 + i] = (_Float16)v;
+                put(idx, l * 8 + i, v);
             }
         }
     }
@@ -125,8 +138,9 @@ struct Packer {
 }  // namespace
 
 void gdb_pack_mfma_section(const float* fp32, float* out) {
-    Packer p{fp32, out};
+    Packer p{fp32, out, out + XLO_OFF};
     memset(out, 0, sizeof(float) * MFMA_FLOATS);
+    memset(out + XLO_OFF, 0, sizeof(float) * XLO_FLOATS);
     auto vrow = [](int s, int h, int i) { return 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); };
     auto lt = [](int n) { return [n](int r) { return r < n ? r : -1; }; };
     auto tile = [](int t, int n) { return [t, n](int r) { return 32 * t + r < n ? 32 * t + r : -1; }; };
@@ -160,25 +174,23 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
     // rows 0..7 = feat_head, row 8 = sigma; both read x
     for (int xt = 0; xt < 2; ++xt)
         for (int s = 0; s < 2; ++s) {
-            _Float16* f = (_Float16*)(out + (size_t)(F_FH + 2 * xt + s) * 256);
             for (int l = 0; l < 64; ++l) {
                 int r = l & 31, h = l >> 5;
                 for (int i = 0; i < 8; ++i) {
                     int col = 32 * xt + vrow(s, h, i);
                     float v = r < GDB_CV ? fp32[PW_FH_W + r * GDB_HID + col] : (r == GDB_CV ? fp32[PW_SIG_W + col] : 0.f);
-                    f[l * 8 + i] = (_Float16)v;
+                    p.put(F_FH + 2 * xt + s, l * 8 + i, v);
                 }
             }
         }
     p.table(TB_FC, PW_FC_B, 1, lt(GDB_IM));
     for (int ot = 0; ot < 2; ++ot) p.table(TD_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
     {   // F_FHB: rows 0..7 feat_head bias, row 8 sigma bias, at element 4 of half 0
-        _Float16* f = (_Float16*)(out + (size_t)F_FHB * 256);
         for (int l = 0; l < 64; ++l) {
             int r = l & 31, h = l >> 5;
             for (int i = 0; i < 8; ++i) {
                 float v = (h == 0 && i == 4) ? (r < GDB_CV ? fp32[PW_FH_B + r] : (r == GDB_CV ? fp32[PW_SIG_B] : 0.f)) : 0.f;
-                f[l * 8 + i] = (_Float16)v;
+                p.put(F_FHB, l * 8 + i, v);
             }
         }
     }
@@ -189,7 +201,7 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
     // ---- f32-MFMA section ----------------------------------------------------------------------------------------
     float* sec = out + MFMA_FLOATS;
     memset(sec, 0, sizeof(float) * F32SEC_FLOATS);
-    Packer p32{fp32, sec};
+    Packer p32{fp32, sec, nullptr};
     // step `st` counted from quad q0: element (st & 3) of quad q0 + (st >> 2); kcol(h) -> column of W or -1
     auto step = [&](int q0, int st, int wOff, int ld, auto rowmap, auto kcol) {
         for (int l = 0; l < 64; ++l) {
@@ -276,7 +288,7 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // at which twelve one-wave workgroups fit a CU (the LDS allocation granule is 1280 B: tools/ubench/simd_map.hip).
 // (The f32 path stages the 4 direction values as fp32 rows: 35 rows.)
 constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND;
-template <int PREC> constexpr int stage_v() { return (NBLEND + (PREC == GDB_PREC_F32 ? 4 : 2)) * 32; }  // floats per (wave, view): 4224 / 4480 B
+template <int PREC> constexpr int stage_v() { return (NBLEND + (PREC != GDB_PREC_F16 ? 4 : 2)) * 32; }  // floats per (wave, view): 4224 / 4480 B
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
 constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
@@ -341,6 +353,56 @@ __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx
     return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
 }
 #define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
+
+// ---- split-f16 operands (GDB_PREC_F32X) --------------------------------------------------------------------------------
+// An MFMA operand fragment is one half8 (X = false: GDB_PREC_F16) or a hi/lo pair of them (X = true) with hi + lo ≈ the fp32
+// value to about 22 bits; a product is then lo·hi + hi·lo + hi·hi, three v_mfma_f32_32x32x16_f16 into the same fp32
+// accumulator (the lo·lo term, 2^-22 of the product, is dropped).  Low parts of values below 2^-4 are f16 subnormals: the
+// matrix pipe and v_cvt_pkrtz honour them (tools/ubench/mfma_denorm.hip).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float relu1(float x);
+template <bool X> struct Frag;
+template <> struct Frag<false> { half8 hi; };
+template <> struct Frag<true> { half8 hi, lo; };
+template <bool X>
+__device__ __forceinline__ Frag<X> load_fragx(const float* __restrict__ mf, int idx, int lane) {
+    Frag<X> r;
+    r.hi = load_frag(mf, idx, lane);
+    if constexpr (X) r.lo = load_frag(mf + XLO_OFF, idx, lane);
+    return r;
+}
+template <bool X>
+__device__ __forceinline__ f32x16 mm(const Frag<X>& a, const Frag<X>& b, f32x16 c) {
+    if constexpr (X) {  // small terms first
+        c = MFMA(a.lo, b.hi, c);
+        c = MFMA(a.hi, b.lo, c);
+    }
+    return MFMA(a.hi, b.hi, c);
+}
+// hi = f16(v) (towards zero), lo = f16(v - hi): two v_cvt_pkrtz and two subtractions per pair of values
+__device__ __forceinline__ Frag<true> split8(const float v[8]) {
+    Frag<true> r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const half2v hp = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]));
+        const half2v lp = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2 * p] - (float)hp.x, v[2 * p + 1] - (float)hp.y));
+        r.hi[2 * p] = hp.x; r.hi[2 * p + 1] = hp.y;
+        r.lo[2 * p] = lp.x; r.lo[2 * p + 1] = lp.y;
+    }
+    return r;
+}
+// k-step S of an accumulator tile as the next layer's B operand, either form
+template <int S, bool RELU, bool X>
+__device__ __forceinline__ Frag<X> accf(const f32x16& a) {
+    if constexpr (X) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = RELU ? relu1(a[8 * S + i]) : a[8 * S + i];
+        return split8(v);
+    } else {
+        return Frag<false>{acc_frag<S, RELU>(a)};
+    }
+}
 // ReLU as exactly one instruction: written as fmaxf(x, 0) hipcc first canonicalises an MFMA output with v_max x, x, x
 // (IEEE-mode maxnum wants quieted inputs) — two instructions per ReLU in every per-view pass.  A signed integer max on the
 // bit pattern is the same function (negative floats, -0 included, have the sign bit set) and needs no canonical input.
@@ -476,9 +538,10 @@ extern __shared__ float4 smem4[];
 // This lane's 12 staged feature values (channels 8s+4h+e, the accumulator rows it owns) and, for half
 // 0, the 4 direction values; from them the two f16 operand fragments of the per-view tail vector
 // tv[32] = [feat ⊕ rgb 19 | 0 | dir 4 at 24..27 | 0].
-struct Tail { float fv[12]; half8 T0, T1; };
-__device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, int h) {
-    Tail t;
+template <bool X> struct Tail { float fv[12]; Frag<X> T0, T1; };
+template <bool X>
+__device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j, int h) {
+    Tail<X> t;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -486,16 +549,26 @@ __device__ __forceinline__ Tail load_tail(const float* __restrict__ st, int j, i
             int ch = 8 * s + 4 * h + e;
             t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
         }
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-    const unsigned* su = (const unsigned*)st;
-    const unsigned d01 = h == 0 ? su[(ROW_DIR + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(ROW_DIR + 1) * 32 + j] : 0u;
-    const half2v p01 = __builtin_bit_cast(half2v, d01), p23 = __builtin_bit_cast(half2v, d23);
+    if constexpr (X) {  // the direction code is staged as four fp32 rows (as for GDB_PREC_F32)
+        float v1[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t.T0[i] = (_Float16)t.fv[i];
+        for (int i = 0; i < 3; ++i) v1[i] = t.fv[8 + i];  // channels 16..18 (half 0) / zeros (half 1)
+        v1[3] = h == 0 ? 1.f : 0.f;                        // tv[19] is padding: constant one that carries view_fc's bias
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t.T1[i] = (_Float16)t.fv[8 + i];  // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
-    t.T1[4] = p01.x; t.T1[5] = p01.y; t.T1[6] = p23.x; t.T1[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
-    t.T1[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
+        for (int i = 0; i < 4; ++i) v1[4 + i] = h == 0 ? st[(ROW_DIR + i) * 32 + j] : 0.f;  // dir sits at tv[24..27], owned by half 0
+        t.T0 = split8(t.fv);
+        t.T1 = split8(v1);
+    } else {
+        const unsigned* su = (const unsigned*)st;
+        const unsigned d01 = h == 0 ? su[(ROW_DIR + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(ROW_DIR + 1) * 32 + j] : 0u;
+        const half2v p01 = __builtin_bit_cast(half2v, d01), p23 = __builtin_bit_cast(half2v, d23);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t.T0.hi[i] = (_Float16)t.fv[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.T1.hi[i] = (_Float16)t.fv[8 + i];  // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
+        t.T1.hi[4] = p01.x; t.T1.hi[5] = p01.y; t.T1.hi[6] = p23.x; t.T1.hi[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
+        t.T1.hi[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
+    }
     return t;
 }
 
@@ -506,8 +579,9 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
 }
-__device__ __forceinline__ f32x16 view_g(const Tail& t, const half8 a_view) {
-    f32x16 g = MFMA(a_view, t.T1, zero16());
+template <bool X>
+__device__ __forceinline__ f32x16 view_g(const Tail<X>& t, const Frag<X>& a_view) {
+    f32x16 g = mm<X>(a_view, t.T1, zero16());
 #pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = t.fv[i] + relu1(g[i]);
 #pragma unroll
@@ -691,7 +765,7 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
             for (int e = 0; e < 4; ++e) st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
         st[(ROW_FEAT + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
         if (h == 0) st[(ROW_FEAT + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
-        if (PREC == GDB_PREC_F32) {  // four fp32 rows; both halves computed the same code, each stores two of them
+        if (PREC != GDB_PREC_F16) {  // four fp32 rows; both halves computed the same code, each stores two of them
             st[(ROW_DIR + 2 * h) * 32 + j] = h ? dir[2] : dir[0];
             st[(ROW_DIR + 2 * h + 1) * 32 + j] = h ? dir[3] : dir[1];
         } else if (h == 0) {
@@ -731,32 +805,36 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // without this each phase's first MFMA waits a full L2 round trip.
 // Outputs per lane (j, h): bacc[i] = blended channel 16h+i of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
 // channel 4h+i, sig = sigma pre-activation (valid in half 0).
+template <bool X>
 __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const float vox[4], int lane, int j,
                                               int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
     const int V = f.V;
-    constexpr int STAGE_V = stage_v<GDB_PREC_F16>();
-    half8 H1;  // k-step 1 of the [vox | im] operand: this half's 4 voxel channels, then the constant one
+    constexpr int STAGE_V = stage_v<X ? GDB_PREC_F32X : GDB_PREC_F16>();
+    Frag<X> H1;  // k-step 1 of the [vox | im] operand: this half's 4 voxel channels, then the constant one
+    {   // element 4 carries the biases of lr0, weight.0, feat_head and sigma (weights there are zero for half 1)
+        const float v[8] = {vox[0], vox[1], vox[2], vox[3], 1.f, 0.f, 0.f, 0.f};
+        if constexpr (X) H1 = split8(v);
+        else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) H1[i] = (_Float16)0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) H1[i] = (_Float16)vox[i];
-    H1[4] = (_Float16)1.f;  // carries the biases of lr0, weight.0, feat_head and sigma (weights there are zero for half 1)
+            for (int i = 0; i < 8; ++i) H1.hi[i] = (_Float16)v[i];
+        }
+    }
     f32x16 base;
-    half8 a_view, a_ga0, a_ga1;
+    Frag<X> a_view, a_ga0, a_ga1;
     f32x16 w_agg;
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
-        a_view = load_frag(mf, F_VIEW, lane_o);
-        const half8 gv0 = load_frag(mf, F_GVAR, lane_o), gv1 = load_frag(mf, F_GVAR + 1, lane_o);
-        const half8 gm0 = load_frag(mf, F_GMEAN, lane_o), gm1 = load_frag(mf, F_GMEAN + 1, lane_o);
-        a_ga0 = load_frag(mf, F_GA, lane_o); a_ga1 = load_frag(mf, F_GA + 1, lane_o);  // next phase
+        a_view = load_fragx<X>(mf, F_VIEW, lane_o);
+        const Frag<X> gv0 = load_fragx<X>(mf, F_GVAR, lane_o), gv1 = load_fragx<X>(mf, F_GVAR + 1, lane_o);
+        const Frag<X> gm0 = load_fragx<X>(mf, F_GMEAN, lane_o), gm1 = load_fragx<X>(mf, F_GMEAN + 1, lane_o);
+        a_ga0 = load_fragx<X>(mf, F_GA, lane_o); a_ga1 = load_fragx<X>(mf, F_GA + 1, lane_o);  // next phase
         w_agg = load_tab(mf, TD_AGG, h_o);
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            const Tail tl = load_tail(stage + (size_t)v * STAGE_V, j, h);
-            f32x16 g = view_g(tl, a_view);
+            const Tail<X> tl = load_tail<X>(stage + (size_t)v * STAGE_V, j, h);
+            f32x16 g = view_g<X>(tl, a_view);
             float inv = frcp((float)(v + 1));
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -770,27 +848,27 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
         for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
         m2[12] = 1.f;  // spare slot 24 of the variance operand: constant one that carries global_fc's bias
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-        base = MFMA(gv0, (acc_frag<0, false>(m2)), zero16());
-        base = MFMA(gv1, (acc_frag<1, false>(m2)), base);
-        base = MFMA(gm0, (acc_frag<0, false>(mean)), base);
-        base = MFMA(gm1, (acc_frag<1, false>(mean)), base);
+        base = mm<X>(gv0, accf<0, false, X>(m2), zero16());
+        base = mm<X>(gv1, accf<1, false, X>(m2), base);
+        base = mm<X>(gm0, accf<0, false, X>(mean), base);
+        base = mm<X>(gm1, accf<1, false, X>(mean), base);
     }
     PHASE_FENCE();
     STAMP(3);
     f32x16 agg, im;
-    half8 fc0, fc1;
+    Frag<X> fc0, fc1;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
-        fc0 = load_frag(mf, F_FC, lane_o); fc1 = load_frag(mf, F_FC + 1, lane_o);  // next phase
+        fc0 = load_fragx<X>(mf, F_FC, lane_o); fc1 = load_fragx<X>(mf, F_FC + 1, lane_o);  // next phase
         im = load_tab(mf, TB_FC, h_o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            const f32x16 g = view_g(load_tail(stage + (size_t)v * STAGE_V, j, h), a_view);
-            const half8 g0 = acc_frag<0, false>(g), g1 = acc_frag<1, false>(g);
-            f32x16 G = MFMA(a_ga0, g0, base);
-            G = MFMA(a_ga1, g1, G);
+            const f32x16 g = view_g<X>(load_tail<X>(stage + (size_t)v * STAGE_V, j, h), a_view);
+            const Frag<X> g0 = accf<0, false, X>(g), g1 = accf<1, false, X>(g);
+            f32x16 G = mm<X>(a_ga0, g0, base);
+            G = mm<X>(a_ga1, g1, G);
             float sp = dot16_relu(G, w_agg);
             float sv = relu1(sp + __shfl_xor(sp, 32) + b_agg);  // nerf.py:79
             float mn = fmaxf(mx, sv);
@@ -805,38 +883,38 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
         for (int i = 0; i < 16; ++i) agg[i] *= r;
     }
     PHASE_FENCE();
-    half8 H0, lr0, lr1, lr2, lr3;
+    Frag<X> H0, lr0, lr1, lr2, lr3;
     {   LANE_KEYS();  // im = fc(agg)   nerf.py:82
-        lr0 = load_frag(mf, F_LR0, lane_o); lr1 = load_frag(mf, F_LR0 + 1, lane_o);  // next phase
-        lr2 = load_frag(mf, F_LR0 + 2, lane_o); lr3 = load_frag(mf, F_LR0 + 3, lane_o);
-        im = MFMA(fc0, (acc_frag<0, false>(agg)), im);
-        im = MFMA(fc1, (acc_frag<1, false>(agg)), im);
-        H0 = acc_frag<0, true>(im);
+        lr0 = load_fragx<X>(mf, F_LR0, lane_o); lr1 = load_fragx<X>(mf, F_LR0 + 1, lane_o);  // next phase
+        lr2 = load_fragx<X>(mf, F_LR0 + 2, lane_o); lr3 = load_fragx<X>(mf, F_LR0 + 3, lane_o);
+        im = mm<X>(fc0, accf<0, false, X>(agg), im);
+        im = mm<X>(fc1, accf<1, false, X>(agg), im);
+        H0 = accf<0, true, X>(im);
     }
     PHASE_FENCE();
     STAMP(4);
-    half8 X00, X01, X10, X11, fhb, fh0, fh1, fh2, fh3;
+    Frag<X> X00, X01, X10, X11, fhb, fh0, fh1, fh2, fh3;
     {   LANE_KEYS();  // x = ReLU(lr0([vox | im]))   nerf.py:100-101
-        fhb = load_frag(mf, F_FHB, lane_o); fh0 = load_frag(mf, F_FH, lane_o); fh1 = load_frag(mf, F_FH + 1, lane_o);  // next phase
-        fh2 = load_frag(mf, F_FH + 2, lane_o); fh3 = load_frag(mf, F_FH + 3, lane_o);
-        f32x16 x0 = MFMA(lr0, H0, zero16());
-        x0 = MFMA(lr1, H1, x0);
-        X00 = acc_frag<0, true>(x0); X01 = acc_frag<1, true>(x0);
-        f32x16 x1 = MFMA(lr2, H0, zero16());
-        x1 = MFMA(lr3, H1, x1);
-        X10 = acc_frag<0, true>(x1); X11 = acc_frag<1, true>(x1);
+        fhb = load_fragx<X>(mf, F_FHB, lane_o); fh0 = load_fragx<X>(mf, F_FH, lane_o); fh1 = load_fragx<X>(mf, F_FH + 1, lane_o);  // next phase
+        fh2 = load_fragx<X>(mf, F_FH + 2, lane_o); fh3 = load_fragx<X>(mf, F_FH + 3, lane_o);
+        f32x16 x0 = mm<X>(lr0, H0, zero16());
+        x0 = mm<X>(lr1, H1, x0);
+        X00 = accf<0, true, X>(x0); X01 = accf<1, true, X>(x0);
+        f32x16 x1 = mm<X>(lr2, H0, zero16());
+        x1 = mm<X>(lr3, H1, x1);
+        X10 = accf<0, true, X>(x1); X11 = accf<1, true, X>(x1);
     }
     PHASE_FENCE();
-    half8 wa0, wa1, wa2, wa3, wb0, wb1;
+    Frag<X> wa0, wa1, wa2, wa3, wb0, wb1;
     {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        wa0 = load_frag(mf, F_W0A + 0, lane_o); wa1 = load_frag(mf, F_W0A + 1, lane_o);  // next phase
-        wa2 = load_frag(mf, F_W0A + 2, lane_o); wa3 = load_frag(mf, F_W0A + 3, lane_o);
-        wb0 = load_frag(mf, F_W0B + 0, lane_o); wb1 = load_frag(mf, F_W0B + 1, lane_o);
-        f32x16 fh = MFMA(fhb, H1, zero16());
-        fh = MFMA(fh0, X00, fh);
-        fh = MFMA(fh1, X01, fh);
-        fh = MFMA(fh2, X10, fh);
-        fh = MFMA(fh3, X11, fh);
+        wa0 = load_fragx<X>(mf, F_W0A + 0, lane_o); wa1 = load_fragx<X>(mf, F_W0A + 1, lane_o);  // next phase
+        wa2 = load_fragx<X>(mf, F_W0A + 2, lane_o); wa3 = load_fragx<X>(mf, F_W0A + 3, lane_o);
+        wb0 = load_fragx<X>(mf, F_W0B + 0, lane_o); wb1 = load_fragx<X>(mf, F_W0B + 1, lane_o);
+        f32x16 fh = mm<X>(fhb, H1, zero16());
+        fh = mm<X>(fh0, X00, fh);
+        fh = mm<X>(fh1, X01, fh);
+        fh = mm<X>(fh2, X10, fh);
+        fh = mm<X>(fh3, X11, fh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fhv[i] = relu1(fh[i]);
         sig = fh[4];
@@ -844,32 +922,32 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     PHASE_FENCE();
     // shared part of weight.0: columns on x and on [vox | im]   nerf.py:106-109
     f32x16 hs0, hs1;
-    half8 wc0, wc1, wc2, wc3, wd0, wd1;
+    Frag<X> wc0, wc1, wc2, wc3, wd0, wd1;
     {   LANE_KEYS();
-        wc0 = load_frag(mf, F_W0A + 4, lane_o); wc1 = load_frag(mf, F_W0A + 5, lane_o);  // next phase
-        wc2 = load_frag(mf, F_W0A + 6, lane_o); wc3 = load_frag(mf, F_W0A + 7, lane_o);
-        wd0 = load_frag(mf, F_W0B + 2, lane_o); wd1 = load_frag(mf, F_W0B + 3, lane_o);
-        hs0 = MFMA(wa0, X00, zero16());
-        hs0 = MFMA(wa1, X01, hs0);
-        hs0 = MFMA(wa2, X10, hs0);
-        hs0 = MFMA(wa3, X11, hs0);
-        hs0 = MFMA(wb0, H0, hs0);
-        hs0 = MFMA(wb1, H1, hs0);
+        wc0 = load_fragx<X>(mf, F_W0A + 4, lane_o); wc1 = load_fragx<X>(mf, F_W0A + 5, lane_o);  // next phase
+        wc2 = load_fragx<X>(mf, F_W0A + 6, lane_o); wc3 = load_fragx<X>(mf, F_W0A + 7, lane_o);
+        wd0 = load_fragx<X>(mf, F_W0B + 2, lane_o); wd1 = load_fragx<X>(mf, F_W0B + 3, lane_o);
+        hs0 = mm<X>(wa0, X00, zero16());
+        hs0 = mm<X>(wa1, X01, hs0);
+        hs0 = mm<X>(wa2, X10, hs0);
+        hs0 = mm<X>(wa3, X11, hs0);
+        hs0 = mm<X>(wb0, H0, hs0);
+        hs0 = mm<X>(wb1, H1, hs0);
     }
     PHASE_FENCE();
-    half8 c00, c01, c10, c11;
+    Frag<X> c00, c01, c10, c11;
     f32x16 w20, w21;
     {   LANE_KEYS();
         // operands of the per-view blend pass (next phase; loop-invariant there: loaded once per slot, not per view)
-        c00 = load_frag(mf, F_W0C + 0, lane_o); c01 = load_frag(mf, F_W0C + 1, lane_o);
-        c10 = load_frag(mf, F_W0C + 2, lane_o); c11 = load_frag(mf, F_W0C + 3, lane_o);
+        c00 = load_fragx<X>(mf, F_W0C + 0, lane_o); c01 = load_fragx<X>(mf, F_W0C + 1, lane_o);
+        c10 = load_fragx<X>(mf, F_W0C + 2, lane_o); c11 = load_fragx<X>(mf, F_W0C + 3, lane_o);
         w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o);
-        hs1 = MFMA(wc0, X00, zero16());
-        hs1 = MFMA(wc1, X01, hs1);
-        hs1 = MFMA(wc2, X10, hs1);
-        hs1 = MFMA(wc3, X11, hs1);
-        hs1 = MFMA(wd0, H0, hs1);
-        hs1 = MFMA(wd1, H1, hs1);
+        hs1 = mm<X>(wc0, X00, zero16());
+        hs1 = mm<X>(wc1, X01, hs1);
+        hs1 = mm<X>(wc2, X10, hs1);
+        hs1 = mm<X>(wc3, X11, hs1);
+        hs1 = mm<X>(wd0, H0, hs1);
+        hs1 = mm<X>(wd1, H1, hs1);
     }
     PHASE_FENCE();
     STAMP(5);
@@ -881,17 +959,17 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
             const float* st = stage + (size_t)v * STAGE_V;
-            const Tail t = load_tail(st, j, h);
-            const half8 T0 = t.T0, T1 = t.T1;
+            const Tail<X> t = load_tail<X>(st, j, h);
+            const Frag<X>& T0 = t.T0; const Frag<X>& T1 = t.T1;
             float up;
             {
-                f32x16 hv = MFMA(c00, T0, hs0);
-                hv = MFMA(c01, T1, hv);
+                f32x16 hv = mm<X>(c00, T0, hs0);
+                hv = mm<X>(c01, T1, hv);
                 up = dot16_relu(hv, w20);
             }
             {
-                f32x16 hv = MFMA(c10, T0, hs1);
-                hv = MFMA(c11, T1, hv);
+                f32x16 hv = mm<X>(c10, T0, hs1);
+                hv = mm<X>(c11, T1, hv);
                 up += dot16_relu(hv, w21);
             }
             float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
@@ -1152,7 +1230,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
                                          const float vox[4], int lane, int j, int h, float b_agg, float b_w2, unsigned* dbg) {
     float bacc[16], fhv[4], sig;
     if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
-    else slot_mlp_core(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+    else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -1393,7 +1471,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
         PHASE_FENCE();
         float bacc[16], fhv[4], sig;
         if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
-        else slot_mlp_core(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
         const float sig0 = __shfl(sig, j);  // sigma sits in half 0
         if (act) {  // lanes without a sample hold unspecified MLP outputs: keep them out of the sums
             const float al = alpha_of(sig0);
@@ -1529,7 +1607,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_dense(FusedArgs a) {
     {
         float bacc[16], fhv[4];
         if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
-        else slot_mlp_core(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = bacc[i];
 #pragma unroll
@@ -1710,8 +1788,8 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     rc = gdb_check_frame(cfg, fr, true); if (rc) return rc;
     if (!ws || !pw || !bf || (ldo == NOUT && (!depth || !opac))) return gdb_fail(GDB_E_BADARG, "NULL pointer");
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
-    if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32)
-        return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA)", precision);
+    if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X)
+        return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA, 2 = split-f16 operands)", precision);
     if (schedule < 0 || schedule > 3) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..3", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
@@ -1738,7 +1816,9 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.skip = env_skip; a.dbg = g_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream_;
-    return precision == GDB_PREC_F32 ? render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, st) : render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, st);
+    if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, st);
+    if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, ws, schedule, st);
+    return render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,

@@ -397,7 +397,8 @@ class HotPathEngine:
     @_on_device
     def render(self, row_begin: int = 0, row_end: Optional[int] = None, precision: Optional[int] = None, out=None):
         """Fused hot path over bundle-map rows [row_begin,row_end) of every batch item.  precision: None = this engine's
-        default (`self.precision`), 0 = f16 MFMA operands, 1 = fp32 MFMA (the reference's precision)."""
+        default (`self.precision`), 0 = f16 MFMA operands, 1 = fp32 MFMA (the reference's precision), 2 = split-f16 operands
+        (hi + lo pairs, three f16 MFMAs per product: fp32-grade, not bit-exact fp32)."""
         if self.weights is None:
             raise ValueError("load_weights() first")
         f = self._need_frame()

@@ -49,8 +49,9 @@ class Network(nn.Module):
         self.upsampler = Decoder(feat_dim + 3 + self.voxel_dim, 3, num_feats=64, num_layers=self.dec_layers, upscale_factor=self.b_size)
         self.reweighting = nrf.reweighting
         self.hot_path = getattr(nrf, "hot_path", "fused")  # "fused" | "mirrors"
-        # arithmetic of the NeRF MLP in the fused kernel: "f32" (fp32 MFMA, the reference's precision; default) | "f16" (f16 operands)
-        self.precision = {"f32": 1, "f16": 0}[str(getattr(nrf, "precision", "f32"))]
+        # arithmetic of the NeRF MLP in the fused kernel: "f32" (fp32 MFMA, the reference's precision; default) | "f16" (f16 operands) |
+        # "f32x" (split-f16 operand pairs: fp32-grade at close to the f16 rate)
+        self.precision = {"f32": 1, "f16": 0, "f32x": 2}[str(getattr(nrf, "precision", "f32"))]
         # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
         # False keeps the PyTorch-ROCm module.  bundle_size 2 only (one up stage).
         self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2

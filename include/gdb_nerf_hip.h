@@ -199,6 +199,8 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   GDB_PREC_F16  f16 MFMA operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) — narrower than the reference;
  *   GDB_PREC_F32  fp32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain, one rounding per product) —
  *                 the reference's own precision.
+ *   GDB_PREC_F32X split-f16: every MFMA operand as an f16 pair hi + lo (about 22 bits), a product as lo·hi + hi·lo + hi·hi on
+ *                 v_mfma_f32_32x32x16_f16 with fp32 accumulate — fp32-grade (not bit-exact fp32) at close to the f16 rate.
  * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
@@ -211,6 +213,7 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
 #define GDB_PREC_F16 0
 #define GDB_PREC_F32 1
+#define GDB_PREC_F32X 2
 #define GDB_SCHED_AUTO 0
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2

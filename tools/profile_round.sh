@@ -10,7 +10,7 @@ WL=${2:-c2}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for P in f32 f16; do
+for P in ${PRECS:-f32 f32x f16}; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$P -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --workload $WL --precision $P > $OUT/bench_under_trace_$P.json 2> $OUT/trace_$P.log
   bash $ROOT/tools/prof_pmc.sh $TAG/pmc_$P --workload $WL --precision $P > $OUT/pmc_$P.log 2>&1
 done
@@ -18,7 +18,7 @@ python3 - <<PY
 import csv, glob, json, os
 out, wl = "$OUT", "$WL"
 res = {"kernel_stats": {}, "pmc_per_dispatch": {}, "traffic_bytes": {}}
-for p in ("f32", "f16"):
+for p in ("f32", "f32x", "f16"):
     st = glob.glob(os.path.join(out, "trace_" + p, "**", "*kernel_stats.csv"), recursive=True)
     rows = list(csv.DictReader(open(st[0]))) if st else []
     res["kernel_stats"][p] = [{"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
