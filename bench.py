@@ -167,7 +167,7 @@ def cpu_baseline(wl, frame, weights):
                       f"threaded to the row's thread count, element-wise numpy on one thread"}
 
 
-def frame_time_ms(dev):
+def frame_time_ms(dev, precision="f32"):
     """t_frame: whole Network.forward (CNNs on PyTorch-ROCm/MIOpen + the HIP hot path) on DTU eval 512x640, 3 views, random
     init; the reference's protocol (run.py:56-73): synchronise, wall clock, drop the first iterations, mean."""
     from gdb_nerf_amd.configs import make_cfg
@@ -177,7 +177,7 @@ def frame_time_ms(dev):
     batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
              "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
     torch.manual_seed(0)
-    net = make_network(make_cfg("configs/dtu_eval.yaml", [])).eval().to(dev)
+    net = make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.precision", precision])).eval().to(dev)
     times = []
     with torch.no_grad():
         for _ in range(14):
@@ -505,6 +505,7 @@ def main():
             res["peaks_measured"] = {"error": repr(ex)}
         try:
             res["t_frame_ms"] = frame_time_ms(dev)
+            res["t_frame_ms_f32x"] = frame_time_ms(dev, "f32x")   # split-f16 pairs in the fused MLP and in the decoder's convolutions
         except Exception as ex:
             res["t_frame_ms"] = None
             res["t_frame_error"] = repr(ex)

@@ -18,9 +18,15 @@
 // * The up stage is folded on the host: PixelShuffle is a permutation and there is no non-linearity between the 64 -> 256 up
 //   convolution and the 1x1 out_conv, so out_conv o PixelShuffle o up = ONE 3x3 convolution 64 -> 12 (4 sub-pixels x 3 colours;
 //   products summed in fp64, rounded once): 21x fewer flops for that stage, same function up to fp32 rounding.
+// * Split-f16 variant of the convolution (GDB_PREC_F32X, k_conv3x3x): operands as f16 hi + lo pairs (about 22 bits), a product as
+//   lo·hi + hi·lo + hi·hi on v_mfma_f32_32x32x16_f16 with fp32 accumulate — 3 x 32 cycles per 16 K instead of 8 x 64: the matrix
+//   time of a layer falls 5.3x and the kernel becomes a staging / weight-stream problem.  Activations are split when they are
+//   staged into LDS (hi and lo halves of a pixel's 32 channels side by side: the same 128 B as fp32), weights on the host.
 // * Squeeze-excitation: deterministic two-stage channel mean (per-block partial sums, reduced in a fixed order), the two tiny
 //   linears + sigmoid in one workgroup per batch item, and one element-wise pass x += x3 * gate (+ the global residual at the end).
 #include "gdb_internal.h"
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -30,13 +36,18 @@ int gdb_check_cfg(const GdbConfig* c);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float F2 __attribute__((ext_vector_type(2)));
 typedef float F4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef unsigned U2 __attribute__((ext_vector_type(2)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 #define DEC_NF 64    // num_feats (network.py:51)
 #define DEC_G 32     // growth rate (decoder_rdn.py:27)
 #define DEC_CS 128   // channel stride of the dense-block buffer [x | x1 | x2]
 #define DEC_PX 34    // pixels per staged row: 32 + halo
 #define DEC_CHS 34   // floats per staged pixel: 32 channels of the chunk + 2 (bank spread for the 8-byte reads)
+#define DECX_PXD 36  // split-f16 staging: dwords per pixel = 16 (hi halves of 32 channels) + 16 (lo halves) + 4 (bank spread for the 16-byte reads)
 #define DEC_SE_R 4   // SE bottleneck: 64 / 16
 #define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
@@ -46,7 +57,9 @@ typedef float F4 __attribute__((ext_vector_type(4)));
 // (half 1): a lane's two K-steps are two CONSECUTIVE channels, one 8-byte LDS read.)
 static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 9 * 8 * 64 * 2 * nt; }
 struct DecLayout {
-    size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b, total;
+    size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
+    size_t in_wx, blkx[3][3], up_wx;  // the same convolutions as split-f16 fragments (pack_conv_x), behind the fp32 ones
+    size_t total;
 };
 static DecLayout dec_layout(int nlayers) {
     DecLayout L{};
@@ -62,7 +75,14 @@ static DecLayout dec_layout(int nlayers) {
     }
     L.up_w = o; o += conv_floats(64, 1);
     L.up_b = o; o += 32;
-    L.total = (o + 8 * 128 + 63) / 64 * 64;  // + one tap block: the conv kernel's weight prefetch runs one tap ahead
+    L.in_wx = o; o += conv_floats(27, 2);
+    for (int b = 0; b < nlayers; ++b) {
+        L.blkx[b][0] = o; o += conv_floats(64, 1);
+        L.blkx[b][1] = o; o += conv_floats(96, 1);
+        L.blkx[b][2] = o; o += conv_floats(128, 2);
+    }
+    L.up_wx = o; o += conv_floats(64, 1);
+    L.total = (o + 8 * 128 + 63) / 64 * 64;  // + one tap block: the fp32 conv kernel's weight prefetch runs one tap ahead
     return L;
 }
 // w: (cout, cin, 3, 3) row-major as torch stores it
@@ -77,6 +97,27 @@ static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
                             int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 4 * u + 2 * h + e;
                             float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
                             out[(((((size_t)t * nchunk + ch) * 9 + tap) * 8 + u) * 64 + l) * 2 + e] = v;
+                        }
+}
+
+// The same layer as split-f16 A-operand fragments of v_mfma_f32_32x32x16_f16: [tile NT][chunk][tap 9][k-step 2][hi, lo][lane 64][8
+// halfs]; element e of lane (i, h) = W[32 tile + i][32 chunk + 16 k-step + 8 h + e][tap], hi = f16(w), lo = f16(w - hi).  Same
+// size in floats as pack_conv's layout.
+static void pack_conv_x(const float* w, int cout, int cin, int nt, float* out) {
+    const int nchunk = (cin + 31) / 32;
+    _Float16* o = (_Float16*)out;
+    for (int t = 0; t < nt; ++t)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 16 * ks + 8 * h + e;
+                            float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                            const size_t base = ((((size_t)t * nchunk + ch) * 9 + tap) * 2 + ks) * 2;
+                            o[((base + 0) * 64 + l) * 8 + e] = hi;
+                            o[((base + 1) * 64 + l) * 8 + e] = lo;
                         }
 }
 
@@ -107,12 +148,16 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
     memset(out, 0, sizeof(float) * L.total);
     const int cin0 = GDB_CFR + GDB_CV;  // 27
     pack_conv(t[0], DEC_NF, cin0, 2, out + L.in_w);
+    pack_conv_x(t[0], DEC_NF, cin0, 2, out + L.in_wx);
     memcpy(out + L.in_b, t[1], sizeof(float) * DEC_NF);
     for (int b = 0; b < num_layers; ++b) {
         const float* const* q = t + 2 + 5 * b;
         pack_conv(q[0], DEC_G, DEC_NF, 1, out + L.blk[b][0]);
         pack_conv(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blk[b][1]);
         pack_conv(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blk[b][2]);
+        pack_conv_x(q[0], DEC_G, DEC_NF, 1, out + L.blkx[b][0]);
+        pack_conv_x(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blkx[b][1]);
+        pack_conv_x(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blkx[b][2]);
         memcpy(out + L.blk[b][3], q[3], sizeof(float) * DEC_SE_R * DEC_NF);
         memcpy(out + L.blk[b][4], q[4], sizeof(float) * DEC_NF * DEC_SE_R);
     }
@@ -133,6 +178,7 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
             out[L.up_b + 3 * s + o] = (float)acc;
         }
     pack_conv(wf.data(), 12, DEC_NF, 1, out + L.up_w);
+    pack_conv_x(wf.data(), 12, DEC_NF, 1, out + L.up_wx);
     return GDB_OK;
 }
 
@@ -277,6 +323,137 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
     }
 }
 
+
+// Split-f16 variant (GDB_PREC_F32X).  Workgroup = 4 waves = 4 image rows of one 32-pixel column, all on the SAME 32-channel
+// output tile (a 64-channel layer launches its two tiles as separate workgroups).  Per 32-channel chunk of the input the
+// workgroup stages in LDS (a) its rows + halo, each pixel's channels as 32 hi halves then 32 lo halves (pixel stride 36 dwords:
+// the 16-byte B-operand reads of a lane group fall on distinct banks), converted from fp32 on the way in, and (b) the chunk's
+// 36 KiB of weight fragments [18 steps = 9 taps x 2 k-steps][hi, lo][64 lanes][16 B]; a step is then four ds_read_b128 (A hi / lo,
+// B hi / lo) and three MFMAs.  The next chunk's global loads (pixels and weights) are issued before the chunk's MFMAs and
+// converted / stored after them.  Measured alternatives (profiles/r02/decoder_split_f16_variants.txt): weights streamed per wave
+// from L2 into a register ring, 1 or 2 rows per wave — every wave then pulls the chunk's 36 KiB through the CU's texture path
+// (64 B/clk) for 1.7 k cycles of MFMAs and that stream, not the matrix pipe, sets the time (0.43-0.49 ms against 0.42).
+constexpr int DECX_ROWS = 1;   // image rows per wave (2: 86 KB of LDS, one workgroup per CU: slower)
+__global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
+    constexpr int R = DECX_ROWS, TR = 4 * R;
+    constexpr int PIXD = (TR + 2) * DEC_PX * DECX_PXD;   // dwords of the pixel image
+    unsigned* lds = (unsigned*)dsmem;
+    unsigned* wl = lds + PIXD;                           // 18 * 2 * 64 * 4 dwords
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int wrow0 = wid * R;
+    const int nt = (a.cout + 31) / 32;
+    int blk = blockIdx.x;
+    const int t = blk % nt; blk /= nt;
+    const int bx = blk % a.tilesX, by = (blk / a.tilesX) % a.tilesY, b = blk / (a.tilesX * a.tilesY);
+    const int x0 = bx * 32, y0 = by * TR;
+    f32x16 acc[R];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q][r] = bv;
+    }
+    const size_t img = (size_t)b * a.H * a.W;
+    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
+    int soff[NSLOT], loff[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int idx = tid + 256 * s;
+        const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
+        const bool slot = idx < (TR + 2) * DEC_PX * 8;
+        loff[s] = slot ? p * DECX_PXD + 2 * g : -1;
+        soff[s] = (slot && px >= 0 && px < a.W && py >= 0 && py < a.H) ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off + 4 * g) : -1;
+    }
+    const float* inb = a.in + img * a.in_stride;
+    const half8* wsrc = (const half8*)a.w + (size_t)t * a.nchunk * 2304 + tid;   // 2304 half8 per (tile, chunk)
+    F4 pre[NSLOT];
+    half8 wpre[9];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wpre[k] = wsrc[(size_t)ch * 2304 + 256 * k];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int ci = 32 * ch + 4 * (tid & 7);
+            F4 v = {0.f, 0.f, 0.f, 0.f};
+            if (soff[s] >= 0) {
+                const float* src = inb + soff[s] + 32 * ch;
+                if (a.vec && ci + 3 < a.cin) v = *(const F4*)src;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (ci + k < a.cin) v[k] = src[k];
+                }
+            }
+            pre[s] = v;
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+        __syncthreads();  // the previous chunk's reads are done
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *(half8*)(wl + (size_t)(tid + 256 * k) * 4) = wpre[k];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (loff[s] < 0) continue;
+            const F4 v = pre[s];
+            const half2v h01 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+            const half2v h23 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+            const U2 hi = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+            const U2 lo = {__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01.x, v[1] - (float)h01.y)),
+                           __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23.x, v[3] - (float)h23.y))};
+            *(U2*)(lds + loff[s]) = hi;
+            *(U2*)(lds + loff[s] + 16) = lo;
+        }
+        __syncthreads();
+        if (ch + 1 < a.nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            const int tap = st >> 1, ks = st & 1, dy = tap / 3, dx = tap % 3;
+            const half8 ah = *(const half8*)(wl + (size_t)((2 * st) * 64 + lane) * 4);
+            const half8 al = *(const half8*)(wl + (size_t)((2 * st + 1) * 64 + lane) * 4);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const unsigned* bp = lds + (size_t)((wrow0 + q + dy) * DEC_PX + j + dx) * DECX_PXD + 8 * ks + 4 * h;
+                const half8 bh = *(const half8*)bp, bl = *(const half8*)(bp + 16);
+                acc[q] = MFMA16(al, bh, acc[q]);
+                acc[q] = MFMA16(ah, bl, acc[q]);
+                acc[q] = MFMA16(ah, bh, acc[q]);
+            }
+        }
+    }
+    const int x = x0 + j;
+    if (x >= a.W) return;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int y = y0 + wrow0 + q;
+        if (y >= a.H) continue;
+        const size_t pix = img + (size_t)y * a.W + x;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = 32 * t + 8 * g + 4 * h;
+            if (co >= a.cout) continue;
+            F4 v = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (a.rgb) {
+                const int Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = co + k;
+                    if (c < 12) {
+                        const int s = c / 3, o = c - 3 * s;
+                        a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (s >> 1)) * Wo + 2 * x + (s & 1)] = v[k];
+                    }
+                }
+            } else {
+                *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
+                if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
+            }
+        }
+    }
+}
+
 // ---- squeeze-excitation ------------------------------------------------------------------------------------------------
 // partial[b][blk][c] = sum over the block's DEC_RED pixels of T[.][c]; fixed order inside a block (16 pixel lanes per float4 of
 // channels, each in pixel order, then a fixed tree over the lanes), fixed order over blocks in k_se_gate: bit-reproducible.
@@ -346,9 +523,28 @@ static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+static hipError_t launch_convx(const ConvArgs& a, int nt, hipStream_t st) {
+    const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 18 * 2 * 64 * 4);
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (lds > 64 * 1024 && !(done.load() >> dev & 1)) {   // per device, once: more than the default 64 KiB of dynamic LDS
+        e = hipFuncSetAttribute((const void*)k_conv3x3x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(1ull << dev);
+    }
+    hipLaunchKernelGGL(k_conv3x3x, dim3((unsigned)(a.B * a.tilesX * a.tilesY * nt)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, int32_t ld_bundle_feat,
-                          const float* d_packed, int32_t num_layers, void* d_ws, size_t ws_bytes, float* d_rgb_c, void* stream_) {
+                          const float* d_packed, int32_t num_layers, int32_t precision, void* d_ws, size_t ws_bytes, float* d_rgb_c,
+                          void* stream_) {
     int rc = dec_check(cfg, num_layers); if (rc) return rc;
+    if (precision != GDB_PREC_F32 && precision != GDB_PREC_F32X)
+        return gdb_fail(GDB_E_BADARG, "decoder precision %d unsupported (1 = fp32 MFMA, 2 = split-f16 operand pairs)", precision);
+    const bool split = precision == GDB_PREC_F32X;
     if (!shape || !d_bundle_feat || !d_packed || !d_ws || !d_rgb_c) return gdb_fail(GDB_E_BADARG, "NULL pointer");
     const int B = shape->B, H = shape->H, W = shape->W;
     if (B < 1 || H < 1 || W < 1) return gdb_fail(GDB_E_SHAPE, "non-positive bundle map");
@@ -366,6 +562,10 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
         a.B = B; a.H = H; a.W = W; a.tilesX = (W + 31) / 32;
         a.nchunk = (a.cin + 31) / 32;
         a.vec = (a.in_stride % 4 == 0) && (a.in_off % 4 == 0) && (a.cin % 4 == 0) && ((uintptr_t)a.in % 16 == 0);
+        if (split) {
+            a.tilesY = (H + 4 * DECX_ROWS - 1) / (4 * DECX_ROWS);
+            return launch_convx(a, nt, st);
+        }
         a.tilesY = (H + 4 / nt - 1) / (4 / nt);
         return nt == 2 ? launch_conv<2>(a, st) : launch_conv<1>(a, st);
     };
@@ -374,7 +574,7 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     {   // shallow = in_conv(bundle channels n_rgb..Q-1)   decoder_rdn.py:76; written as block 0's x and kept for the global residual
         ConvArgs a{};
         a.in = d_bundle_feat; a.in_stride = ld_bundle_feat; a.in_off = n_rgb; a.cin = Q - n_rgb;
-        a.w = d_packed + L.in_w; a.bias = d_packed + L.in_b;
+        a.w = d_packed + (split ? L.in_wx : L.in_w); a.bias = d_packed + L.in_b;
         a.out = X; a.out_stride = DEC_CS; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.out2 = S; a.out2_stride = DEC_NF;
         CK(conv(a, 2));
     }
@@ -382,11 +582,11 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     for (int b = 0; b < num_layers; ++b) {   // ResidualDenseBlock.forward   decoder_rdn.py:35-41
         ConvArgs a{};
         a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.out = X; a.out_stride = DEC_CS; a.relu = 1;
-        a.cin = DEC_NF; a.w = d_packed + L.blk[b][0]; a.out_off = DEC_NF; a.cout = DEC_G;
+        a.cin = DEC_NF; a.w = d_packed + (split ? L.blkx[b][0] : L.blk[b][0]); a.out_off = DEC_NF; a.cout = DEC_G;
         CK(conv(a, 1));
-        a.cin = DEC_NF + DEC_G; a.w = d_packed + L.blk[b][1]; a.out_off = DEC_NF + DEC_G;
+        a.cin = DEC_NF + DEC_G; a.w = d_packed + (split ? L.blkx[b][1] : L.blk[b][1]); a.out_off = DEC_NF + DEC_G;
         CK(conv(a, 1));
-        a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + L.blk[b][2]; a.out = T; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
+        a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + (split ? L.blkx[b][2] : L.blk[b][2]); a.out = T; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
         CK(conv(a, 2));
         hipLaunchKernelGGL(k_chan_partial, dim3((unsigned)(B * ws.nblk)), dim3(256), 0, st, T, H * W, ws.nblk, part);
         CK(hipGetLastError());
@@ -399,7 +599,7 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     }
     {   // out_conv(PixelShuffle(up(x))) as one folded 64 -> 12 convolution   decoder_rdn.py:79-80
         ConvArgs a{};
-        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.cin = DEC_NF; a.w = d_packed + L.up_w; a.bias = d_packed + L.up_b;
+        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.cin = DEC_NF; a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
         a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
         CK(conv(a, 1));
     }

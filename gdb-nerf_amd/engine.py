@@ -218,10 +218,13 @@ class HotPathEngine:
         self.dec_weights, self.dec_layers = torch.from_numpy(host).to(self.device), int(num_layers)
 
     @_on_device
-    def decode(self, bundle_feat: torch.Tensor) -> torch.Tensor:
+    def decode(self, bundle_feat: torch.Tensor, precision: Optional[int] = None) -> torch.Tensor:
         """Decoder.forward (decoder_rdn.py:67-81) on the frame last prepared: bundle_feat (n_bundles, Q) or the packed
         (n_bundles, Q + 2) render, read in place (channels 3b^2 .. Q-1 are the decoder's input, network.py:170-174) ->
-        rgb_c (B, 3, Ho, Wo)."""
+        rgb_c (B, 3, Ho, Wo).  precision: None = fp32 MFMA unless this engine's `precision` is PREC_F32X or PREC_F16 (then the
+        split-f16 convolutions, fp32-grade), 1 = fp32 MFMA, 2 = split-f16."""
+        if precision is None:
+            precision = _lib.PREC_F32 if self.precision == _lib.PREC_F32 else _lib.PREC_F32X
         if getattr(self, "dec_weights", None) is None:
             raise ValueError("load_decoder_weights() first")
         f = self._need_frame()
@@ -236,7 +239,7 @@ class HotPathEngine:
         b = self.cfg.bundle_size
         rgb_c = torch.empty((f.B, 3, f.H * b, f.W * b), device=self.device)
         _lib.check(self.lib.gdb_decode(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), int(bundle_feat.shape[1]), self.dec_weights.data_ptr(),
-                                       self.dec_layers, self._dec_ws.data_ptr(), self._dec_ws.numel(), rgb_c.data_ptr(), self._stream()))
+                                       self.dec_layers, int(precision), self._dec_ws.data_ptr(), self._dec_ws.numel(), rgb_c.data_ptr(), self._stream()))
         return rgb_c
 
     def set_schedule(self, mode: int) -> None:

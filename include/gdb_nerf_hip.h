@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 2
+#define GDB_ABI_VERSION 3
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -272,10 +272,12 @@ int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers, const flo
 int gdb_decoder_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out_bytes);
 /* d_bundle_feat: the hot path's output rows (B*H*W, ld_bundle_feat >= Q), read in place: the decoder's input is channels
  * 3b² .. Q-1 of every row (network.py:170-174: nerf_feat[:, 3b²:]).  d_rgb_c (B,3,H*b,W*b) = the reference's `rgb_c`; feed it
- * to gdb_merge.  d_workspace: gdb_decoder_workspace_bytes, caller-owned scratch. */
+ * to gdb_merge.  d_workspace: gdb_decoder_workspace_bytes, caller-owned scratch.
+ * precision: GDB_PREC_F32 (fp32 MFMA, the reference's arithmetic) or GDB_PREC_F32X (split-f16 operand pairs, fp32 accumulate:
+ * fp32-grade, the convolutions' matrix time 5.3x shorter); the packed weights hold both forms. */
 int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, int32_t ld_bundle_feat,
-               const float* d_packed_decoder_weights, int32_t num_layers, void* d_workspace, size_t workspace_bytes,
-               float* d_rgb_c, void* stream);
+               const float* d_packed_decoder_weights, int32_t num_layers, int32_t precision, void* d_workspace,
+               size_t workspace_bytes, float* d_rgb_c, void* stream);
 
 #ifdef __cplusplus
 }

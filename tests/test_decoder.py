@@ -37,6 +37,23 @@ def _unpack_conv(packed, cout, cin, nt):
     return w.reshape(cout, cin, 3, 3)
 
 
+def _unpack_conv_x(packed, cout, cin, nt):
+    """Inverse of pack_conv_x: [tile][chunk][tap][k-step][hi, lo][lane][8 halfs] -> (hi, lo) each (cout, cin, 3, 3) as float32."""
+    nchunk = (cin + 31) // 32
+    a = packed[:nt * nchunk * 9 * 2 * 2 * 64 * 4].view(np.float16).reshape(nt, nchunk, 9, 2, 2, 64, 8).astype(np.float32)
+    w = np.zeros((2, cout, cin, 9), np.float32)
+    for t in range(nt):
+        for ch in range(nchunk):
+            for ks in range(2):
+                for l in range(64):
+                    i, h = l & 31, l >> 5
+                    for e in range(8):
+                        co, ci = 32 * t + i, 32 * ch + 16 * ks + 8 * h + e
+                        if co < cout and ci < cin:
+                            w[:, co, ci, :] = a[t, ch, :, ks, :, l, e].T
+    return w[0].reshape(cout, cin, 3, 3), w[1].reshape(cout, cin, 3, 3)
+
+
 def test_packed_decoder_weights_and_the_folded_up_stage():
     """Host logic, no GPU: the operand-order packing is a permutation of the reference's tensors, and the folded 64 -> 12
     convolution (out_conv o PixelShuffle o up-conv, summed in fp64) reproduces the reference's three modules."""
@@ -71,6 +88,23 @@ def test_packed_decoder_weights_and_the_folded_up_stage():
     y = F.conv2d(x, wf, bf, padding=1)                                # (2, 12, 9, 11), channel 3 s + o, s = dy*2 + dx
     got = y.view(2, 2, 2, 3, 9, 11).permute(0, 3, 4, 1, 5, 2).reshape(2, 3, 18, 22)
     assert max_abs(got.numpy(), want.numpy()) <= 2e-6 * float(want.abs().max())
+    o += 32                                                           # folded bias (12 used)
+    # the same convolutions again as split-f16 fragments: hi + lo = the fp32 weight to ~22 bits, hi = f16(w)
+    fp32 = {"in": (0, 64, 27, 2)}
+    q = conv_floats(27, 2) + 64
+    for i in range(3):
+        for name, (cout, cin, nt) in (("c1", (32, 64, 1)), ("c2", (32, 96, 1)), ("c3", (64, 128, 2))):
+            fp32[f"{i}{name}"] = (q, cout, cin, nt); q += conv_floats(cin, nt)
+        q += 512
+    fp32["up"] = (q, 12, 64, 1)
+    for key in ["in"] + [f"{i}{c}" for i in range(3) for c in ("c1", "c2", "c3")] + ["up"]:
+        off, cout, cin, nt = fp32[key]
+        w = _unpack_conv(host[off:], cout, cin, nt)
+        hi, lo = _unpack_conv_x(host[o:], cout, cin, nt)
+        assert np.array_equal(hi, w.astype(np.float16).astype(np.float32)), key
+        assert np.all(np.abs(hi.astype(np.float64) + lo - w) <= np.abs(w) * 2.0 ** -21 + 2.0 ** -25), key
+        o += conv_floats(cin, nt)
+    assert o + 8 * 128 <= n.value
     with pytest.raises(ValueError, match="bundle_size 2"):
         _lib.check(lib.gdb_decoder_packed_floats(C.byref(_lib.GdbConfig(4, 3, 1, 0, 64, 3, 16, 8, 64, 1)), 3, C.byref(n)))
 
@@ -83,8 +117,13 @@ def _engine(B, H, W, sd, layers=3):
     return eng
 
 
+# fp32 MFMA (exact fmaf chains) and the split-f16 convolutions (operand pairs of ~22 bits): both fp32-grade, one bound
+PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["f32", "f32x"])
+
+
 @pytest.mark.gpu
-def test_hip_decoder_matches_the_reference_fixture():
+@PRECS
+def test_hip_decoder_matches_the_reference_fixture(prec):
     f7 = load_golden("F7_network")
     sd = _dec_state(f7)
     x = f7["dec_in"]                                                     # (1, 27, 32, 48)
@@ -94,15 +133,16 @@ def test_hip_decoder_matches_the_reference_fixture():
         bf = torch.zeros((H * W, ld))
         bf[:, 12:39] = torch.from_numpy(x[0]).permute(1, 2, 0).reshape(H * W, 27)
         bf[:, :12] = 7.0                                                 # the fine-RGB channels (and depth / opacity) are not the decoder's
-        got = eng.decode(bf.cuda().contiguous())
+        got = eng.decode(bf.cuda().contiguous(), precision=prec)
         e = max_abs(got.cpu().numpy(), f7["dec_out"])
         print(f"HIP decoder vs the reference's Decoder (F7, ld {ld}): max abs err {e:.3e} on values up to {np.abs(f7['dec_out']).max():.2f}")
         assert e <= 2e-5 * max(1.0, float(np.abs(f7["dec_out"]).max()))
 
 
 @pytest.mark.gpu
+@PRECS
 @pytest.mark.parametrize("B,H,W,layers", [(1, 32, 48, 3), (2, 19, 45, 3), (1, 7, 33, 2), (1, 256, 320, 3), (1, 130, 70, 1)])
-def test_hip_decoder_matches_torch_module(B, H, W, layers):
+def test_hip_decoder_matches_torch_module(B, H, W, layers, prec):
     """Ragged bundle maps (edges inside a 32-pixel tile and inside a row group), batch 2, 1..3 blocks, and the DTU-eval size
     (two rows per wave), against the PyTorch module on the same GPU."""
     torch.manual_seed(3)
@@ -116,10 +156,12 @@ def test_hip_decoder_matches_torch_module(B, H, W, layers):
     bf[:, 12:] = x.permute(0, 2, 3, 1).reshape(B * H * W, 27)
     with torch.no_grad():
         want = dec(x)
-    got = eng.decode(bf)
+    got = eng.decode(bf, precision=prec)
     e, scale = max_abs(got.cpu().numpy(), want.cpu().numpy()), float(want.abs().max())
-    print(f"HIP decoder vs torch ({B},{H},{W}) x{layers}: max abs err {e:.3e}, output scale {scale:.2f}")
+    print(f"HIP decoder (precision {prec}) vs torch ({B},{H},{W}) x{layers}: max abs err {e:.3e}, output scale {scale:.2f}")
     assert e <= 3e-5 * max(1.0, scale)
-    assert torch.equal(got, eng.decode(bf))                               # deterministic (two-stage channel means, no atomics)
+    assert torch.equal(got, eng.decode(bf, precision=prec))               # deterministic (two-stage channel means, no atomics)
     with pytest.raises(ValueError, match="bundle_feat"):
         eng.decode(bf[:-1])
+    with pytest.raises(ValueError, match="precision"):
+        eng.decode(bf, precision=0)

@@ -95,7 +95,7 @@ def _batch(f7, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hot_path,precision,tol", [("mirrors", "f32", 5e-4), ("fused", "f32", 5e-4), ("fused", "f16", 2e-3)])
+@pytest.mark.parametrize("hot_path,precision,tol", [("mirrors", "f32", 5e-4), ("fused", "f32", 5e-4), ("fused", "f32x", 5e-4), ("fused", "f16", 2e-3)])
 def test_network_forward_matches_reference(f7, hot_path, precision, tol):
     """Whole Network.forward on the MI355X (CNNs on PyTorch-ROCm; hot path, cost volume, decoder and merge on the HIP library)
     against the reference's CPU forward with the same checkpoint."""

@@ -22,9 +22,16 @@ def t(fn, n=50):
 with torch.no_grad():
     ms_torch = t(lambda: dec(x))
     ms_torch_perm = t(lambda: dec(bf.view(1, H, W, 39).permute(0, 3, 1, 2)[:, 12:]))   # as Network.forward feeds it (strided view)
-ms_hip = t(lambda: eng.decode(bf))
+ms_hip = t(lambda: eng.decode(bf, precision=1))
+ms_hip_x = t(lambda: eng.decode(bf, precision=2))
+with torch.no_grad():
+    want = dec(x)
+err = {p: float((eng.decode(bf, precision=p) - want).abs().max()) for p in (1, 2)}
 flop = 2 * H * W * 9 * (27 * 64 + 3 * (64 * 32 + 96 * 32 + 128 * 64) + 64 * 256) + 2 * 4 * H * W * 64 * 3
 flop_hip = 2 * H * W * 9 * (27 * 64 + 3 * (64 * 32 + 96 * 32 + 128 * 64) + 64 * 12)
 print(json.dumps({"decoder_ms_torch_miopen": ms_torch, "decoder_ms_torch_from_bundle_rows": ms_torch_perm, "decoder_ms_hip": ms_hip,
                   "reference_GFLOP": flop / 1e9, "hip_GFLOP_after_folding_the_up_stage": flop_hip / 1e9,
-                  "hip_TFLOPs_fp32_mfma": flop_hip / ms_hip / 1e9, "frac_of_157.3": flop_hip / ms_hip / 1e9 / 157.3}))
+                  "hip_TFLOPs_fp32_mfma": flop_hip / ms_hip / 1e9, "frac_of_157.3": flop_hip / ms_hip / 1e9 / 157.3,
+                  "decoder_ms_hip_split_f16": ms_hip_x, "split_f16_TFLOPs_algorithmic": flop_hip / ms_hip_x / 1e9,
+                  "max_abs_err_vs_torch": {"f32": err[1], "f32x": err[2]}, "output_scale": float(want.abs().max()),
+                  "rows_per_wave_env": os.environ.get("GDB_DEC_R")}))

@@ -13,6 +13,7 @@ batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"
          "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
 res = {}
 for name, opts in {"fused (fp32 MFMA) + hip cost volume + hip decoder [default]": [],
+                   "split-f16 pairs (fp32-grade) in the fused MLP and the decoder + hip cost volume": ["nerf.precision", "f32x"],
                    "fused + hip cost volume, torch decoder": ["nerf.hip_decoder", "False"],
                    "fused f16 operands + hip cost volume + hip decoder": ["nerf.precision", "f16"],
                    "fused, torch cost volume, torch decoder": ["mvs.hip_cost_volume", "False", "nerf.hip_decoder", "False"],
