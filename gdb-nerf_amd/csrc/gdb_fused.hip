@@ -1754,8 +1754,8 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
         a.ntiles = fr->B * a.nrows * a.f.planMW;
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
         bool three = false;
-        if constexpr (PREC == GDB_PREC_F16) three = 12 * (solo_lds + pad) <= lds_max;
-        if constexpr (PREC == GDB_PREC_F16) { if (three) e = launch_dense<GDB_PREC_F16, 3>(a, grid, solo_lds + pad, st); }
+        if constexpr (PREC != GDB_PREC_F32) three = 12 * (solo_lds + pad) <= lds_max;
+        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, grid, solo_lds + pad, st); }
         if (!three) e = launch_dense<PREC, 2>(a, grid, solo_lds + pad, st);
     } else if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
