@@ -47,7 +47,7 @@ typedef unsigned U2 __attribute__((ext_vector_type(2)));
 #define DEC_CS 128   // channel stride of the dense-block buffer [x | x1 | x2]
 #define DEC_PX 34    // pixels per staged row: 32 + halo
 #define DEC_CHS 34   // floats per staged pixel: 32 channels of the chunk + 2 (bank spread for the 8-byte reads)
-#define DECX_PXD 36  // split-f16 staging: dwords per pixel = 16 (hi halves of 32 channels) + 16 (lo halves) + 4 (bank spread for the 16-byte reads)
+#define DECX_PXD 20  // split-f16 staging: dwords per pixel = 8 (hi halves of a chunk's 16 channels) + 8 (lo halves) + 4 (bank spread for the 16-byte reads)
 #define DEC_SE_R 4   // SE bottleneck: 64 / 16
 #define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
@@ -100,25 +100,24 @@ static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
                         }
 }
 
-// The same layer as split-f16 A-operand fragments of v_mfma_f32_32x32x16_f16: [tile NT][chunk][tap 9][k-step 2][hi, lo][lane 64][8
-// halfs]; element e of lane (i, h) = W[32 tile + i][32 chunk + 16 k-step + 8 h + e][tap], hi = f16(w), lo = f16(w - hi).  Same
-// size in floats as pack_conv's layout.
+// The same layer as split-f16 A-operand fragments of v_mfma_f32_32x32x16_f16: [tile NT][16-channel chunk][tap 9][hi, lo][lane 64][8
+// halfs]; element e of lane (i, h) = W[32 tile + i][16 chunk + 8 h + e][tap], hi = f16(w), lo = f16(w - hi).  The chunk count is
+// padded to an even number, so the size in floats equals pack_conv's.
 static void pack_conv_x(const float* w, int cout, int cin, int nt, float* out) {
-    const int nchunk = (cin + 31) / 32;
+    const int nchunk = (cin + 31) / 32 * 2;
     _Float16* o = (_Float16*)out;
     for (int t = 0; t < nt; ++t)
         for (int ch = 0; ch < nchunk; ++ch)
             for (int tap = 0; tap < 9; ++tap)
-                for (int ks = 0; ks < 2; ++ks)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e) {
-                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 16 * ks + 8 * h + e;
-                            float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
-                            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-                            const size_t base = ((((size_t)t * nchunk + ch) * 9 + tap) * 2 + ks) * 2;
-                            o[((base + 0) * 64 + l) * 8 + e] = hi;
-                            o[((base + 1) * 64 + l) * 8 + e] = lo;
-                        }
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 16 * ch + 8 * h + e;
+                        float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        const size_t base = (((size_t)t * nchunk + ch) * 9 + tap) * 2;
+                        o[((base + 0) * 64 + l) * 8 + e] = hi;
+                        o[((base + 1) * 64 + l) * 8 + e] = lo;
+                    }
 }
 
 static int dec_check(const GdbConfig* cfg, int nlayers) {
@@ -325,24 +324,37 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
 
 
 // Split-f16 variant (GDB_PREC_F32X).  Workgroup = 4 waves = 4 image rows of one 32-pixel column, all on the SAME 32-channel
-// output tile (a 64-channel layer launches its two tiles as separate workgroups).  Per 32-channel chunk of the input the
-// workgroup stages in LDS (a) its rows + halo, each pixel's channels as 32 hi halves then 32 lo halves (pixel stride 36 dwords:
-// the 16-byte B-operand reads of a lane group fall on distinct banks), converted from fp32 on the way in, and (b) the chunk's
-// 36 KiB of weight fragments [18 steps = 9 taps x 2 k-steps][hi, lo][64 lanes][16 B]; a step is then four ds_read_b128 (A hi / lo,
-// B hi / lo) and three MFMAs.  The next chunk's global loads (pixels and weights) are issued before the chunk's MFMAs and
-// converted / stored after them.  Measured alternatives (profiles/r02/decoder_split_f16_variants.txt): weights streamed per wave
-// from L2 into a register ring, 1 or 2 rows per wave — every wave then pulls the chunk's 36 KiB through the CU's texture path
-// (64 B/clk) for 1.7 k cycles of MFMAs and that stream, not the matrix pipe, sets the time (0.43-0.49 ms against 0.42).
-constexpr int DECX_ROWS = 1;   // image rows per wave (2: 86 KB of LDS, one workgroup per CU: slower)
+// output tile (a 64-channel layer launches its two tiles as separate workgroups).  Per 16-channel chunk of the input (one MFMA
+// K-step) the workgroup stages in LDS (a) its rows + halo, each pixel's channels as 16 hi halves then 16 lo halves (pixel stride
+// 20 dwords: the 16-byte B-operand reads of a lane group fall on distinct banks), converted from fp32 on the way in, and (b) the
+// chunk's 18 KiB of weight fragments [9 taps][hi, lo][64 lanes][16 B]; a tap is then four ds_read_b128 (A hi / lo, B hi / lo) and
+// three MFMAs.  34 KB of LDS per workgroup: four workgroups per CU, so one's staging runs under the others' MFMAs.  The next
+// chunk's global loads (pixels and weights) are issued before the chunk's MFMAs and converted / stored after them.
+// Measured alternatives (profiles/r02/decoder_split_f16_variants.txt): weights streamed per wave from L2 into a register ring, 1
+// or 2 rows per wave — every wave then pulls its weights through the CU's texture path (64 B/clk) and that stream, not the
+// matrix pipe, sets the time (0.43-0.49 ms); 32-channel chunks (66 KB of LDS, two workgroups per CU) 0.37-0.42 ms.  What is left
+// is not matrix time (one MFMA instead of three per product: 0.36 -> 0.32 ms) nor the global loads (none after the first chunk:
+// 0.33 ms) but the two-barrier staging cycle per chunk; see DESIGN.md section 8.
+constexpr int DECX_ROWS = 1;   // image rows per wave
+#ifndef DECX_PF
+#define DECX_PF 1              // taps of LDS operand reads in flight ahead of the MFMAs (1, 2, 3 measured the same)
+#endif
+// VEC: the input rows allow 16-byte loads and the layer's channel count is a multiple of 4 (every layer but in_conv, which reads
+// the 39- / 41-float bundle rows at channel 12).  The staging loads are branch-free — a slot outside the image or beyond the
+// layer's channels loads a valid address and is zeroed when it is converted — so a chunk's loads issue back to back (as
+// predicated branches each slot was its own basic block with its own vmcnt(0)).
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
     constexpr int R = DECX_ROWS, TR = 4 * R;
     constexpr int PIXD = (TR + 2) * DEC_PX * DECX_PXD;   // dwords of the pixel image
+    constexpr int WFRAG = 9 * 2 * 64;                    // half8 per (tile, chunk) of weights
     unsigned* lds = (unsigned*)dsmem;
-    unsigned* wl = lds + PIXD;                           // 18 * 2 * 64 * 4 dwords
+    unsigned* wl = lds + PIXD;                           // 9 * 2 * 64 * 4 dwords
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int wrow0 = wid * R;
     const int nt = (a.cout + 31) / 32;
+    const int nchunk = 2 * a.nchunk;                     // 16-channel chunks (a.nchunk counts 32-channel ones)
     int blk = blockIdx.x;
     const int t = blk % nt; blk /= nt;
     const int bx = blk % a.tilesX, by = (blk / a.tilesX) % a.tilesY, b = blk / (a.tilesX * a.tilesY);
@@ -356,70 +368,97 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
         for (int q = 0; q < R; ++q) acc[q][r] = bv;
     }
     const size_t img = (size_t)b * a.H * a.W;
-    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    int soff[NSLOT], loff[NSLOT];
+    constexpr int NPIX = (TR + 2) * DEC_PX * 4;          // (pixel, 4-channel group) slots of a chunk
+    constexpr int NSLOT = (NPIX + 255) / 256;
+    constexpr int NW = (WFRAG + 255) / 256;
+    int soff[NSLOT];       // float offset of the slot's pixel inside the input (clamped into the image), channel group excluded
+    int loff[NSLOT];       // dword offset of the slot's hi halves in LDS (lo halves 8 dwords further)
+    unsigned inimg = 0;    // bit s: the slot exists and its pixel lies inside the image
+    const int g4 = 4 * (tid & 3);   // the slot's 4-channel group inside a chunk: (tid + 256 s) & 3 = tid & 3
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = tid + 256 * s;
-        const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+        const int p = idx >> 2, rx = p % DEC_PX, ry = p / DEC_PX;
         const int px = x0 - 1 + rx, py = y0 - 1 + ry;
-        const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        loff[s] = slot ? p * DECX_PXD + 2 * g : -1;
-        soff[s] = (slot && px >= 0 && px < a.W && py >= 0 && py < a.H) ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off + 4 * g) : -1;
+        const bool slot = idx < NPIX;
+        loff[s] = slot ? p * DECX_PXD + (g4 >> 1) : -1;
+        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
+        inimg |= (in ? 1u : 0u) << s;
+        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
     }
     const float* inb = a.in + img * a.in_stride;
-    const half8* wsrc = (const half8*)a.w + (size_t)t * a.nchunk * 2304 + tid;   // 2304 half8 per (tile, chunk)
+    const half8* wsrc = (const half8*)a.w + (size_t)t * nchunk * WFRAG;
     F4 pre[NSLOT];
-    half8 wpre[9];
+    half8 wpre[NW];
     auto fetch = [&](int ch) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wpre[k] = wsrc[(size_t)ch * 2304 + 256 * k];
+        for (int k = 0; k < NW; ++k) wpre[k] = wsrc[(size_t)ch * WFRAG + min(tid + 256 * k, WFRAG - 1)];
+        const int ci = 16 * ch + g4;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            const int ci = 32 * ch + 4 * (tid & 7);
-            F4 v = {0.f, 0.f, 0.f, 0.f};
-            if (soff[s] >= 0) {
-                const float* src = inb + soff[s] + 32 * ch;
-                if (a.vec && ci + 3 < a.cin) v = *(const F4*)src;
-                else {
+            if (VEC) {
+                pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (ci + k < a.cin) v[k] = src[k];
-                }
+                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
             }
-            pre[s] = v;
         }
     };
+    // zero what the branch-free loads should not have brought: pixels outside the image, channels beyond the layer's
+    auto masked = [&](int s, int ch) {
+        const int ci = 16 * ch + g4;
+        F4 v = pre[s];
+        const bool in = (inimg >> s) & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+        return v;
+    };
     fetch(0);
-    for (int ch = 0; ch < a.nchunk; ++ch) {
+    for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // the previous chunk's reads are done
 #pragma unroll
-        for (int k = 0; k < 9; ++k) *(half8*)(wl + (size_t)(tid + 256 * k) * 4) = wpre[k];
+        for (int k = 0; k < NW; ++k)
+            if (tid + 256 * k < WFRAG) *(half8*)(wl + (size_t)(tid + 256 * k) * 4) = wpre[k];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             if (loff[s] < 0) continue;
-            const F4 v = pre[s];
+            const F4 v = masked(s, ch);
             const half2v h01 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
             const half2v h23 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
             const U2 hi = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
             const U2 lo = {__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01.x, v[1] - (float)h01.y)),
                            __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23.x, v[3] - (float)h23.y))};
             *(U2*)(lds + loff[s]) = hi;
-            *(U2*)(lds + loff[s] + 16) = lo;
+            *(U2*)(lds + loff[s] + 8) = lo;
         }
         __syncthreads();
-        if (ch + 1 < a.nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
-#pragma unroll
-        for (int st = 0; st < 18; ++st) {
-            const int tap = st >> 1, ks = st & 1, dy = tap / 3, dx = tap % 3;
-            const half8 ah = *(const half8*)(wl + (size_t)((2 * st) * 64 + lane) * 4);
-            const half8 al = *(const half8*)(wl + (size_t)((2 * st + 1) * 64 + lane) * 4);
+        if (ch + 1 < nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
+        // operand ring: the four ds_read_b128 of tap + DECX_PF are issued before the MFMAs of a tap (left to the compiler each
+        // read sat directly in front of its MFMA behind an lgkmcnt wait: an LDS round trip per 96 cycles of matrix work)
+        half8 opA[DECX_PF + 1][2], opB[DECX_PF + 1][R][2];
+        auto load_ops = [&](int tap, int slot) {
+            const int dy = tap / 3, dx = tap % 3;
+            opA[slot][0] = *(const half8*)(wl + (size_t)((2 * tap) * 64 + lane) * 4);
+            opA[slot][1] = *(const half8*)(wl + (size_t)((2 * tap + 1) * 64 + lane) * 4);
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                const unsigned* bp = lds + (size_t)((wrow0 + q + dy) * DEC_PX + j + dx) * DECX_PXD + 8 * ks + 4 * h;
-                const half8 bh = *(const half8*)bp, bl = *(const half8*)(bp + 16);
-                acc[q] = MFMA16(al, bh, acc[q]);
-                acc[q] = MFMA16(ah, bl, acc[q]);
-                acc[q] = MFMA16(ah, bh, acc[q]);
+                const unsigned* bp = lds + (size_t)((wrow0 + q + dy) * DEC_PX + j + dx) * DECX_PXD + 4 * h;
+                opB[slot][q][0] = *(const half8*)bp;
+                opB[slot][q][1] = *(const half8*)(bp + 8);
+            }
+        };
+#pragma unroll
+        for (int tap = 0; tap < DECX_PF; ++tap) load_ops(tap, tap % (DECX_PF + 1));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + DECX_PF < 9) load_ops(tap + DECX_PF, (tap + DECX_PF) % (DECX_PF + 1));
+            __builtin_amdgcn_sched_barrier(0);   // keeps the reads above the MFMAs below (a compiler-only memory fence did not)
+            const int cur = tap % (DECX_PF + 1);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                acc[q] = MFMA16(opA[cur][1], opB[cur][q][0], acc[q]);
+                acc[q] = MFMA16(opA[cur][0], opB[cur][q][1], acc[q]);
+                acc[q] = MFMA16(opA[cur][0], opB[cur][q][0], acc[q]);
             }
         }
     }
@@ -524,17 +563,20 @@ static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
 }
 
 static hipError_t launch_convx(const ConvArgs& a, int nt, hipStream_t st) {
-    const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 18 * 2 * 64 * 4);
+    const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 9 * 2 * 64 * 4);
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (lds > 64 * 1024 && !(done.load() >> dev & 1)) {   // per device, once: more than the default 64 KiB of dynamic LDS
-        e = hipFuncSetAttribute((const void*)k_conv3x3x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)k_conv3x3x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done.fetch_or(1ull << dev);
     }
-    hipLaunchKernelGGL(k_conv3x3x, dim3((unsigned)(a.B * a.tilesX * a.tilesY * nt)), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY * nt));
+    if (a.vec) hipLaunchKernelGGL(k_conv3x3x<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_conv3x3x<false>, grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

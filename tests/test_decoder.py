@@ -38,19 +38,18 @@ def _unpack_conv(packed, cout, cin, nt):
 
 
 def _unpack_conv_x(packed, cout, cin, nt):
-    """Inverse of pack_conv_x: [tile][chunk][tap][k-step][hi, lo][lane][8 halfs] -> (hi, lo) each (cout, cin, 3, 3) as float32."""
-    nchunk = (cin + 31) // 32
-    a = packed[:nt * nchunk * 9 * 2 * 2 * 64 * 4].view(np.float16).reshape(nt, nchunk, 9, 2, 2, 64, 8).astype(np.float32)
+    """Inverse of pack_conv_x: [tile][16-channel chunk][tap][hi, lo][lane][8 halfs] -> (hi, lo) each (cout, cin, 3, 3) as float32."""
+    nchunk = (cin + 31) // 32 * 2
+    a = packed[:nt * nchunk * 9 * 2 * 64 * 4].view(np.float16).reshape(nt, nchunk, 9, 2, 64, 8).astype(np.float32)
     w = np.zeros((2, cout, cin, 9), np.float32)
     for t in range(nt):
         for ch in range(nchunk):
-            for ks in range(2):
-                for l in range(64):
-                    i, h = l & 31, l >> 5
-                    for e in range(8):
-                        co, ci = 32 * t + i, 32 * ch + 16 * ks + 8 * h + e
-                        if co < cout and ci < cin:
-                            w[:, co, ci, :] = a[t, ch, :, ks, :, l, e].T
+            for l in range(64):
+                i, h = l & 31, l >> 5
+                for e in range(8):
+                    co, ci = 32 * t + i, 16 * ch + 8 * h + e
+                    if co < cout and ci < cin:
+                        w[:, co, ci, :] = a[t, ch, :, :, l, e].T
     return w[0].reshape(cout, cin, 3, 3), w[1].reshape(cout, cin, 3, 3)
 
 
