@@ -201,6 +201,8 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *                 the reference's own precision.
  *   GDB_PREC_F32X split-f16: every MFMA operand as an f16 pair hi + lo (about 22 bits), a product as lo·hi + hi·lo + hi·hi on
  *                 v_mfma_f32_32x32x16_f16 with fp32 accumulate — fp32-grade (not bit-exact fp32) at close to the f16 rate.
+ *                 Like GDB_PREC_F16 it assumes activations inside the f16 range: the high half saturates at 65504 (the low
+ *                 half then carries the rest up to about twice that; beyond it the value is clipped).
  * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
