@@ -235,22 +235,44 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
     const size_t img = (size_t)b * a.H * a.W;
     // staging plan of this thread: the (pixel, 4-channel group) slots it fills are the same for every chunk, so their source
     // offsets and LDS addresses are computed once (the divisions by 34 are not cheap, and VALU cycles are matrix cycles on the
-    // fp32 datapath)
+    // fp32 datapath).  The loads are branch-free (a slot outside the image or beyond the layer's channels loads a valid address
+    // and is zeroed when it is stored) and run one chunk ahead: a chunk's global loads are issued before the previous chunk's
+    // MFMAs and stored to LDS after them — issued at the top of their own chunk they left every workgroup waiting out an L2 / HBM
+    // round trip per chunk, which the 32-channel layers' 2.5 waves per SIMD could not cover (48 us for 22 us of MFMAs).
     constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    int soff[NSLOT];   // float offset of the slot's source inside the input (row stride included), -1: outside the image / no slot
-    int loff[NSLOT];   // float offset of the slot in LDS
+    int soff[NSLOT];   // float offset of the slot's pixel inside the input (clamped into the image), channel group excluded
+    int loff[NSLOT];   // float offset of the slot in LDS, -1: no slot
+    unsigned inimg = 0;
+    const int g4 = 4 * (tid & 7);   // the slot's 4-channel group inside a chunk: (tid + 256 s) & 7 = tid & 7
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = tid + 256 * s;
-        const int g = idx & 7, p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+        const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
         const int px = x0 - 1 + rx, py = y0 - 1 + ry;
         const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        loff[s] = slot ? p * DEC_CHS + 4 * g : -1;
-        soff[s] = (slot && px >= 0 && px < a.W && py >= 0 && py < a.H) ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off + 4 * g) : -1;
+        loff[s] = slot ? p * DEC_CHS + g4 : -1;
+        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
+        inimg |= (in ? 1u : 0u) << s;
+        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
     }
     const float* inb = a.in + img * a.in_stride;   // (a frame's input is < 2^31 floats: checked on the host)
     const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2 + (size_t)lane * 2;
     const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
+    F4 pre[NSLOT];
+    auto fetch = [&](int ch) {
+        const int ci = 32 * ch + g4;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (a.vec) pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
+            }
+        }
+    };
+    // (Measured for the 64-channel layers too, although the chunk in flight costs them two of their six waves per SIMD: decoder
+    // 0.804 -> 0.771 ms with the loads ahead in both, 0.780 in the 32-channel layers only.)
+    fetch(0);
     // weights: the next tap's 8 packets are loaded while the current tap's 16 MFMAs run (L2 latency under the matrix pipe)
     F2 wn[8];
 #pragma unroll
@@ -261,20 +283,16 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             if (loff[s] < 0) continue;
-            const int ci = 32 * ch + 4 * (tid & 7);  // the slot's 4-channel group: (tid + 256 s) & 7 = tid & 7
-            F4 v = {0.f, 0.f, 0.f, 0.f};
-            if (soff[s] >= 0) {
-                const float* src = inb + soff[s] + 32 * ch;
-                if (a.vec && ci + 3 < a.cin) v = *(const F4*)src;
-                else {
+            const int ci = 32 * ch + g4;
+            const bool in = (inimg >> s) & 1;
+            F4 v = pre[s];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (ci + k < a.cin) v[k] = src[k];
-                }
-            }
+            for (int k = 0; k < 4; ++k) v[k] = (in && (a.vec ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
             F2* dst = (F2*)(lds + loff[s]);  // 8-byte aligned (DEC_CHS is even)
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
+        if (ch + 1 < a.nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
