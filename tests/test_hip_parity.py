@@ -459,6 +459,24 @@ def test_split_f16_precision_tracks_fp32(H, W, V, S, adaptive):
         assert max_abs(npy(x[1]), npy(ref[1])) <= 2e-5 * float(ref[1].abs().max()) and max_abs(npy(x[2]), npy(ref[2])) <= 1e-5
 
 
+@pytest.mark.parametrize("wscale,fscale", [(1.0, 1.0), (3.0, 1.0), (0.2, 8.0), (2.0, 30.0)])
+def test_split_f16_precision_is_relative(wscale, fscale):
+    """The split keeps ~22 bits of every operand whatever its magnitude (inside the f16 range): with the MLP weights and the
+    image features scaled, |f32x - f32| stays a few 1e-7 of the output's scale.  (Activations reach a few hundred at the last
+    pair of scales; f16 operands lose three more digits there.)"""
+    frame = synthetic.make_frame(96, 128, V=3, B=1, seed=5)
+    frame["img_feat"] = (frame["img_feat"] * np.float32(fscale)).astype(np.float32)
+    w = {k: (v * np.float32(wscale)).astype(np.float32) for k, v in synthetic.make_nerf_weights(seed=8).items()}
+    eng = engine_for(frame, w, max_num_samples=4, is_adaptive=True)
+    ref = eng.render(precision=1)[0].clone()
+    x = eng.render(precision=2)[0].clone()
+    h = eng.render(precision=0)[0].clone()
+    scale = float(ref.abs().max())
+    ex, eh = max_abs(npy(x), npy(ref)) / scale, max_abs(npy(h), npy(ref)) / scale
+    print(f"weights x{wscale}, features x{fscale}: output scale {scale:.3g}, |f32x - f32| / scale {ex:.2e}, |f16 - f32| / scale {eh:.2e}")
+    assert np.isfinite(npy(x)).all() and ex <= 5e-6 and ex * 30 <= max(eh, 1e-5)   # (observed 1.8e-7 .. 2.4e-6; the softmax scores grow with the scales)
+
+
 @pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),
                                                           (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu")])
 def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
