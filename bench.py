@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run for this long before the W warm-up steps, so clocks have ramped (0 = off)")
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--smax", type=int, default=0, help="override the workload's S_max (SURVEY §8(a): sweep 3, 6, 8; 0 = the workload's own)")
+    ap.add_argument("--sampling", default="config", choices=["config", "adaptive", "fixed"], help="override the workload's sampling mode")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"], help="arithmetic of the NeRF MLP in the fused kernel")
     ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
@@ -267,7 +269,11 @@ def main():
     if args.streams > 1 and (args.path != "fused" or world > 1):
         raise SystemExit("--streams > 1 is for the fused path at N = 1")
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.smax or args.sampling != "config":   # S_max sweep: a variant of the workload, named as such in config.workload
+        wl["S"] = args.smax or wl["S"]
+        wl["adaptive"] = wl["adaptive"] if args.sampling == "config" else args.sampling == "adaptive"
+        wl["desc"] += f" [override: S_max {wl['S']} {'adaptive' if wl['adaptive'] else 'fixed'}]"
     Ho, Wo, V = wl["Ho"], wl["Wo"], wl["V"]
     H, W = Ho // 2, Wo // 2
     weights_np = synthetic.make_nerf_weights(seed=0)
