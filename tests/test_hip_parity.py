@@ -355,7 +355,7 @@ def test_fused_matches_unfused_at_full_size(mode):
 
 def test_c2_full_size_against_the_oracle():
     """BASELINE.json configs[1] at its full size, directly against the CPU oracle (one oracle frame takes a couple of seconds):
-    the fp32 operator chain and the fused kernel under both schedules and both precisions, sample counts included."""
+    the fp32 operator chain and the fused kernel under the three schedules and the three precisions, sample counts included."""
     frame = synthetic.make_frame(512, 640, V=3, seed=0)   # the frame bench.py renders
     w = synthetic.make_nerf_weights(seed=0)
     with np.errstate(all="ignore"):
@@ -506,11 +506,11 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
 
 
 def test_engines_with_different_settings_interleave():
-    """the ABI is reentrant — no process-global state.  Four engines (both schedules x both precisions)
-    on two HIP streams, their calls interleaved, must each reproduce their solo result bit for bit."""
-    frames = [synthetic.make_frame(128, 160, V=3, seed=40 + i) for i in range(4)]
+    """the ABI is reentrant — no process-global state.  Six engines (schedules x precisions, each precision
+    and each schedule twice) on two HIP streams, their calls interleaved, must each reproduce their solo result bit for bit."""
+    frames = [synthetic.make_frame(128, 160, V=3, seed=40 + i) for i in range(6)]
     w = synthetic.make_nerf_weights(seed=6)
-    modes = [(1, 0), (2, 1), (3, 0), (3, 1)]
+    modes = [(1, 0), (2, 1), (3, 0), (3, 1), (1, 2), (2, 2)]
     engs = [engine_for(f, w, m, max_num_samples=4, is_adaptive=True) for f, m in zip(frames, modes)]
     solo = [[t.clone() for t in e.render()] for e in engs]
     torch.cuda.synchronize()
