@@ -300,6 +300,7 @@ struct FusedArgs {
     const float* pw;  // packed weights (fp32 section, then MFMA sections)
     int row_begin, nrows, nseg, nsegs, ntiles, alias, skip;  // skip: timing-only ablation bits (diagnostic build)
     int ldo;          // floats per output row of bf: NOUT, or NOUT + 2 for the packed layout [feat | depth | opacity]
+    int wave_floats;  // dense schedule: floats of LDS per wave (a workgroup may hold two waves, each with its own area)
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     unsigned* dbg;    // diagnostic build only
 };
@@ -1536,14 +1537,18 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
 // The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by
 // looking back over the earlier samples, weighted sums by a segmented suffix sum in log2(S_max) shuffle steps, the bundle's
 // first lane normalises and hands the row to the LDS transpose.  utils.py:35-41, :109-119, network.py:83-89.
-template <int PREC, int WPS>
-__global__ void __launch_bounds__(64, WPS) k_render_dense(FusedArgs a) {
+// NWG = waves per workgroup (independent windows, no workgroup barrier anywhere): LDS is allocated in 1280-byte granules, and
+// two waves' areas in one allocation can fit where single ones lose a wave per CU to the rounding (fp32 staging, V = 3: 13,440 B
+// per wave = 11 one-wave workgroups per CU, but 6 two-wave ones = 12 waves).
+template <int PREC, int WPS, int NWG>
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     const DevFrame& f = a.f;
-    float* stage = (float*)smem4;
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     unsigned* dbg = a.dbg; (void)dbg;
-    const int chunk = (a.ntiles + 7) >> 3;  // XCD-aware tile order: one contiguous band of (row, window) tiles per XCD
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int chunk = ((a.ntiles + NWG - 1) / NWG + 7) >> 3;  // XCD-aware tile order: one contiguous band of (row, window) tiles per XCD
+    const int tile = ((blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * NWG + wv;
     if (tile >= a.ntiles) return;
     const int win = tile % f.planMW, rr = tile / f.planMW;
     const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
@@ -1699,12 +1704,25 @@ static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hip
     return hipGetLastError();
 }
 
+// lds: bytes per wave (a multiple of 16); two waves per workgroup where that puts more waves on a CU (1280-byte LDS granules)
 template <int PREC, int WPS>
-static hipError_t launch_dense(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
+    const size_t gran = 1280, cap = 160 * 1024;
+    const size_t one = cap / ((lds + gran - 1) / gran * gran), two = 2 * (cap / ((2 * lds + gran - 1) / gran * gran));
+    a.wave_floats = (int)(lds / sizeof(float));
+    if (two > one) {
+        static std::atomic<unsigned long long> done2{0};
+        hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 2>, done2);
+        if (e != hipSuccess) return e;
+        const unsigned grid = (unsigned)(((a.ntiles + 1) / 2 + 7) / 8 * 8);
+        hipLaunchKernelGGL((k_render_dense<PREC, WPS, 2>), dim3(grid), dim3(128), 2 * lds, st, a);
+        return hipGetLastError();
+    }
     static std::atomic<unsigned long long> done{0};
-    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS>, done);
+    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 1>, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_render_dense<PREC, WPS>), dim3(grid), dim3(64), lds, st, a);
+    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((k_render_dense<PREC, WPS, 1>), dim3(grid), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -1755,8 +1773,8 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
         bool three = false;
         if constexpr (PREC != GDB_PREC_F32) three = 12 * (solo_lds + pad) <= lds_max;
-        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, grid, solo_lds + pad, st); }
-        if (!three) e = launch_dense<PREC, 2>(a, grid, solo_lds + pad, st);
+        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, (solo_lds + pad + 15) / 16 * 16, st); }
+        if (!three) e = launch_dense<PREC, 2>(a, (solo_lds + pad + 15) / 16 * 16, st);
     } else if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
         // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
@@ -1810,7 +1828,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
-    a.dbg = nullptr; a.skip = 0;
+    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     a.skip = env_skip; a.dbg = g_dbg;

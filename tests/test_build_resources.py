@@ -20,19 +20,13 @@ def usage():
 def test_fused_kernels_keep_their_data_out_of_private_memory(usage):
     """Round 1's "packed f32 corrupts lanes 48..63" was a private-memory (scratch) round trip of a weight struct that hipcc
     introduced to form op_sel operand pairs (reproducer -DGDB_XP_PK=1).  Every instantiation of the c2-class
-    kernel must have a zero-size private segment, and no fused kernel may spill vector registers — with ONE recorded exception:
-    the dense schedule at GDB_PREC_F32X sits exactly on the 168-register bound of three waves per SIMD and spills one dword
-    (a plain scratch_store_dword in the prologue / scratch_load_dword in the composite, read in the ISA: nothing like the masked
-    x4 store + misaligned x2 load of the round-1 pattern); it buys c4 204 -> 174 us and is covered by every dense-f32x parity test."""
+    kernel must have a zero-size private segment, and no fused kernel may spill vector registers."""
     fused = {k: v for k, v in usage["gdb_fused.hip"].items() if "k_render" in k}
     assert len(fused) >= 12, sorted(fused)     # 3 precisions x (3 slot-wave variants + segment-wave + dense kernels)
     for name, u in fused.items():
         if "k_render_fused" in name:
             assert u["scratch_bytes_per_lane"] == 0, (name, u)
-        if "k_render_denseILi2ELi3E" in name:
-            assert u["vgpr_spill"] <= 1 and u["scratch_bytes_per_lane"] <= 8, (name, u)
-        else:
-            assert u["vgpr_spill"] == 0, (name, u)
+        assert u["vgpr_spill"] == 0, (name, u)
 
 
 def test_occupancy_the_schedules_are_designed_for(usage):
