@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # GDB_NERF_LIB selects another build of the same ABI (tools/: the -DGDB_DIAG diagnostic library and A/B flag variants are
 # built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
 
@@ -61,6 +61,7 @@ _SIGNATURES = {
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gdb_render_bundles_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gdb_merge": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "gdb_merge_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "gdb_decoder_packed_floats": (C.c_int, [_CFG, C.c_int32, C.POINTER(C.c_size_t)]),
     "gdb_pack_decoder_weights": (C.c_int, [_CFG, C.c_int32, C.POINTER(_P), _P]),
     "gdb_decoder_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),

@@ -68,22 +68,33 @@ enum {
 // operand: it carries features acc_row(r, 0) (half 0) and acc_row(r, 1) (half 1) of the lane's sample, and the next
 // layer runs one MFMA per register with no conversion and no lane movement.  A "step" is one MFMA's A operand (64
 // floats, W[out row i][k of (step, h)]); four consecutive steps are stored as one float4 per lane (a "quad", 1 KiB).
+//
+// The two layers with <= 16 output rows (fc 32 -> 16; feat_head + sigma 64 -> 9) run on v_mfma_f32_16x16x4_f32 instead
+// (same FLOP rate, half the padding: 32 cycles per 16 rows x 16 samples x 4 k).  Lane l supplies A[row l & 15][k = l >> 4]
+// and B[k = l >> 4][sample l & 15]; D register r of lane l is row 4 (l >> 4) + r of sample l & 15.  A "k-group" g of such
+// a layer takes the input register PAIR (2g, 2g + 1): v_permlane16_swap turns the pair into the B operands of samples
+// 0..15 and 16..31, whose k order is [reg 2g half 0, reg 2g+1 half 0, reg 2g half 1, reg 2g+1 half 1]; a second swap of
+// the two D tiles leaves lane (j, h) with output rows 8h + r and 8h + 4 + r of its own sample, and the rows are permuted
+// on the host so that those are the features the next layer's operand wants there.  Four k-groups = one quad.
 enum {
     Q_VIEW = 0,    // view_fc on dir: 2 steps (step s carries dir 2s + h)
-    Q_GVAR = 1,    // global_fc columns [19,38) on var: 12 steps (register r of the 19-vector in accumulator layout)
-    Q_GMEAN = 4,   // global_fc columns [38,57) on mean
-    Q_GA = 7,      // global_fc columns [0,19) on g_v
-    Q_FC = 10,     // fc on the aggregated 32-vector: 16 steps
-    Q_LR0 = 14,    // [out tile 2][3 quads]: 8 steps on im (registers 0..7), then 4 on vox (step i carries channel i + 4h)
-    Q_FH = 20,     // rows 0..7 feat_head, row 8 sigma: 32 steps on x ([x tile][register])
-    Q_W0A = 28,    // weight.0 columns [0,64) on x: [out tile 2][8 quads]
-    Q_W0B = 44,    // weight.0 columns [64,88) on [vox | im]: [out tile 2][3 quads], step order as Q_LR0
-    Q_W0C = 50,    // weight.0 columns [88,111) on the per-view tail: [out tile 2][4 quads]: 12 steps on feat ⊕ rgb, 2 on dir
-    NQUADS = 58
+    Q_GVAR = 1,    // global_fc columns [19,38) on var: 12 steps (register r of the 19-vector in accumulator layout); the slots
+                   // (r = 8..10, half 1) - channels 20..22, which do not exist - carry the MEAN columns of channels 16..18
+    Q_GMEAN = 4,   // global_fc columns [38,54) on mean channels 0..15: 8 steps
+    Q_GA = 6,      // global_fc columns [0,19) on g_v: 12 steps
+    Q_FC = 9,      // fc on the aggregated 32-vector: 8 k-groups (16x16x4 form)
+    Q_LR0 = 11,    // [out tile 2][3 quads]: 8 steps on im (registers 0..7), then 4 on vox (step i carries channel i + 4h)
+    Q_FH = 17,     // rows feat_head 0..7, +sigma, -sigma on x: 16 k-groups (16x16x4 form)
+    Q_W0A = 21,    // weight.0 columns [0,64) on x: [out tile 2][8 quads]
+    Q_W0B = 37,    // weight.0 columns [64,88) on [vox | im]: [out tile 2][3 quads], step order as Q_LR0
+    Q_W0C = 43,    // weight.0 columns [88,111) on the per-view tail: [out tile 2][3 quads]: 12 steps on the tail registers
+                   // (feat (+) rgb in accumulator layout, with dir 0..3 in the slots (r = 8..11, half 1))
+    NQUADS = 49
 };
-enum {  // fp32 tables in accumulator layout [h][16] (bias tables initialise a layer's accumulator), then scalars
-    T32_VIEW = NQUADS * 256, T32_GLOB = T32_VIEW + 32, T32_FC = T32_GLOB + 32, T32_LR0 = T32_FC + 32 /* 2 tiles */,
-    T32_FH = T32_LR0 + 64, T32_W0 = T32_FH + 32 /* 2 tiles */, T32_AGG = T32_W0 + 64, T32_W2 = T32_AGG + 32 /* 2 tiles */,
+enum {  // fp32 tables: [h][16] in 32x32 accumulator layout (bias tables initialise a layer's accumulator), [lane][4] for the
+        // 16x16x4 layers (T16_*), then scalars
+    T32_VIEW = NQUADS * 256, T32_GLOB = T32_VIEW + 32, T16_FC = T32_GLOB + 32, T32_LR0 = T16_FC + 256 /* 2 tiles */,
+    T16_FH = T32_LR0 + 64, T32_W0 = T16_FH + 256 /* 2 tiles */, T32_AGG = T32_W0 + 64, T32_W2 = T32_AGG + 32 /* 2 tiles */,
     S32_BAGG = T32_W2 + 64, S32_BW2 = S32_BAGG + 1,
     F32SEC_FLOATS = (S32_BW2 + 1 + 63) / 64 * 64
 };
@@ -209,14 +220,34 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
             sec[(size_t)(q0 + (st >> 2)) * 256 + l * 4 + (st & 3)] = (orow >= 0 && col >= 0) ? fp32[wOff + orow * ld + col] : 0.f;
         }
     };
+    // k-group g of a 16x16x4 layer, counted from quad q0: lane l carries value(row l & 15, k = l >> 4); the k order of the
+    // swapped register pair (2g, 2g + 1) is [2g half 0, 2g+1 half 0, 2g half 1, 2g+1 half 1]
+    auto group = [&](int q0, int g, auto value) {
+        for (int l = 0; l < 64; ++l) {
+            const int k = l >> 4, reg = 2 * g + (k & 1), h = k >> 1;
+            sec[(size_t)(q0 + (g >> 2)) * 256 + l * 4 + (g & 3)] = value(l & 15, reg, h);
+        }
+    };
+    auto table16 = [&](int off, auto value) {  // D layout of a 16x16x4 tile: register r of lane l = row 4 (l >> 4) + r
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) sec[off + l * 4 + r] = value(4 * (l >> 4) + r);
+    };
     auto c19k = [](int r, int base) { return [=](int h) { int k = acc_row(r, h); return k < GDB_CFR ? base + k : -1; }; };
     for (int s = 0; s < 2; ++s) step(Q_VIEW, s, PW_VIEW_W, 4, lt(GDB_CFR), [=](int h) { return 2 * s + h; });
     for (int r = 0; r < 12; ++r) {
-        step(Q_GVAR, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, GDB_CFR));
-        step(Q_GMEAN, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, 2 * GDB_CFR));
+        // var registers; half 1 of registers 8..10 (no such channel) carries mean channels 16..18, moved there by the kernel
+        step(Q_GVAR, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), [=](int h) {
+            if (h == 1 && r >= 8 && r <= 10) return 2 * GDB_CFR + 16 + (r - 8);
+            int k = acc_row(r, h); return k < GDB_CFR ? GDB_CFR + k : -1; });
+        if (r < 8) step(Q_GMEAN, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, 2 * GDB_CFR));
         step(Q_GA, r, PW_GLOB_W, 3 * GDB_CFR, lt(GDB_GF), c19k(r, 0));
     }
-    for (int r = 0; r < 16; ++r) step(Q_FC, r, PW_FC_W, GDB_GF, lt(GDB_IM), [=](int h) { return acc_row(r, h); });
+    // fc: output row m of the 16x16x4 tile computes feature pi(m), chosen so that after the D swap lane (j, h) holds im
+    // registers 0..7 (features acc_row(r, h)): rows 0..3 -> 0..3, 4..7 -> 8..11, 8..11 -> 4..7, 12..15 -> 12..15
+    auto pi_fc = [](int m) { return (m & 3) + ((m >> 2) == 1 ? 8 : (m >> 2) == 2 ? 4 : (m >> 2) * 4); };
+    for (int g = 0; g < 8; ++g)
+        group(Q_FC, g, [&](int m, int reg, int h) { return fp32[PW_FC_W + pi_fc(m) * GDB_GF + acc_row(reg, h)]; });
+    table16(T16_FC, [&](int m) { return fp32[PW_FC_B + pi_fc(m)]; });
     // [vox | im] operand: steps 0..7 = im registers (features acc_row(r, h) < 16), steps 8..11 = vox channel i + 4h
     auto hk = [](int st, int base) {
         return [=](int h) { return st < 8 ? base + GDB_CV + acc_row(st, h) : base + (st - 8) + 4 * h; };
@@ -228,29 +259,37 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
         }
         for (int st = 0; st < 32; ++st)
             step(Q_W0A + 8 * ot, st, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h) { return 32 * (st >> 4) + acc_row(st & 15, h); });
-        for (int r = 0; r < 12; ++r) step(Q_W0C + 4 * ot, r, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), c19k(r, GDB_HID + GDB_HD));
-        for (int s = 0; s < 2; ++s)
-            step(Q_W0C + 4 * ot, 12 + s, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h) { return GDB_HID + GDB_HD + GDB_CFR + 2 * s + h; });
+        // tail registers: feat (+) rgb in accumulator layout; half 1 of registers 8..11 (channels 20..23: none) carries dir 0..3
+        for (int r = 0; r < 12; ++r)
+            step(Q_W0C + 3 * ot, r, PW_W0_W, GDB_W0IN, tile(ot, GDB_HID), [=](int h) {
+                if (h == 1 && r >= 8) return GDB_HID + GDB_HD + GDB_CFR + (r - 8);
+                int k = acc_row(r, h); return k < GDB_CFR ? GDB_HID + GDB_HD + k : -1; });
     }
-    for (int st = 0; st < 32; ++st)  // rows 0..7 feat_head, row 8 sigma
-        for (int l = 0; l < 64; ++l) {
-            int i = l & 31, h = l >> 5, col = 32 * (st >> 4) + acc_row(st & 15, h);
-            sec[(size_t)(Q_FH + (st >> 2)) * 256 + l * 4 + (st & 3)] =
-                i < GDB_CV ? fp32[PW_FH_W + i * GDB_HID + col] : (i == GDB_CV ? fp32[PW_SIG_W + col] : 0.f);
-        }
+    // feat_head + sigma on x (register xi of X carries feature 32 (xi >> 4) + acc_row(xi & 15, h)).  Output rows: 0..3 feat_head
+    // 0..3, 8..11 feat_head 4..7 (after the D swap lane (j, h) holds channels 4h..4h+3), row 4 = +sigma, row 5 = -sigma: both are
+    // ReLU'd with the rest before the swap and sigma = ReLU(s) - ReLU(-s) (exact), so that the swap reads VALU results only.
+    auto fh_w = [&](int m, int col) {
+        if (m < 4) return fp32[PW_FH_W + m * GDB_HID + col];
+        if (m >= 8 && m < 12) return fp32[PW_FH_W + (m - 4) * GDB_HID + col];
+        if (m == 4) return fp32[PW_SIG_W + col];
+        if (m == 5) return -fp32[PW_SIG_W + col];
+        return 0.f;
+    };
+    for (int g = 0; g < 16; ++g)
+        group(Q_FH, g, [&](int m, int reg, int h) { return fh_w(m, 32 * (reg >> 4) + acc_row(reg & 15, h)); });
+    table16(T16_FH, [&](int m) {
+        if (m < 4) return fp32[PW_FH_B + m];
+        if (m >= 8 && m < 12) return fp32[PW_FH_B + m - 4];
+        if (m == 4) return fp32[PW_SIG_B];
+        if (m == 5) return -fp32[PW_SIG_B];
+        return 0.f; });
     p32.table(T32_VIEW, PW_VIEW_B, 1, lt(GDB_CFR));
     p32.table(T32_GLOB, PW_GLOB_B, 1, lt(GDB_GF));
-    p32.table(T32_FC, PW_FC_B, 1, lt(GDB_IM));
     for (int ot = 0; ot < 2; ++ot) {
         p32.table(T32_LR0 + 32 * ot, PW_LR0_B, 1, tile(ot, GDB_HID));
         p32.table(T32_W0 + 32 * ot, PW_W0_B, 1, tile(ot, GDB_HID));
         p32.table(T32_W2 + 32 * ot, PW_W2_W, 1, tile(ot, GDB_HID));
     }
-    for (int h = 0; h < 2; ++h)
-        for (int r = 0; r < 16; ++r) {
-            int o = acc_row(r, h);
-            sec[T32_FH + h * 16 + r] = o < GDB_CV ? fp32[PW_FH_B + o] : (o == GDB_CV ? fp32[PW_SIG_B] : 0.f);
-        }
     p32.table(T32_AGG, PW_AGG_W, 1, lt(GDB_GF));
     sec[S32_BAGG] = fp32[PW_AGG_B];
     sec[S32_BW2] = fp32[PW_W2_B];
@@ -1023,23 +1062,72 @@ __device__ __forceinline__ f32x16 chain32(const float* __restrict__ m32, int q0,
     load_quads<NS>(m32, q0, lane, w);
     return chain32w<NS>(w, b, acc);
 }
-// This lane's B-operand registers of one staged view: the 19-vector feat ⊕ rgb in accumulator layout (register 4s+e
-// carries channel 8s + 4h + e; channels >= 19 are zeros) and the two direction steps (step s carries dir 2s + h).
+// v_mfma_f32_16x16x4_f32 for the two layers with <= 16 output rows (see the section layout above)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_permlane16_swap_b32 a, b: the odd 16-lane rows of a trade places with the even rows of b, i.e. afterwards
+//   a = [a.row0, b.row0, a.row2, b.row2]   b = [a.row1, b.row1, a.row3, b.row3]
+// Inline asm, not __builtin_amdgcn_permlane16_swap: hipcc 7.2 hands back the builtin's FIRST result for both elements of the
+// pair (read in the ISA: both uses name the same register).  The compiler's hazard recogniser does not look inside inline asm
+// (DESIGN.md 4.1), so (1) every operand here must be the result of a plain VALU instruction, never of an MFMA, and (2) the
+// s_nop pairs are the wait states hipcc itself places around the builtin (VALU write -> permlane read, permlane write -> use).
+__device__ __forceinline__ void swap16_4(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+}
+// v_permlane32_swap_b32 a, b: the upper 32 lanes of a trade places with the lower 32 lanes of b (same caveats)
+__device__ __forceinline__ void swap32_3(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2));
+}
+__device__ __forceinline__ f32x4 load_tab16(const float* __restrict__ m32, int off, int lane) {
+    return ldu_pin<f32x4>(m32 + off, (unsigned)lane * 16u);
+}
+// One 16-row layer on v_mfma_f32_16x16x4_f32: NG k-groups over the 2 NG VALU-produced registers x (swapped IN PLACE: x is dead
+// afterwards as a 32x32 operand), accumulators d0 (samples 0..15) / d1 (samples 16..31) start from the bias table.
+template <int NG>
+__device__ __forceinline__ void chain16(const f32x4* __restrict__ w, float* __restrict__ x, f32x4& d0, f32x4& d1) {
+    static_assert(NG % 4 == 0, "k-groups come in quads");
+#pragma unroll
+    for (int g = 0; g < NG; g += 4)
+        swap16_4(x[2 * g], x[2 * g + 1], x[2 * g + 2], x[2 * g + 3], x[2 * g + 4], x[2 * g + 5], x[2 * g + 6], x[2 * g + 7]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        d0 = MFMA16(w[g >> 2][g & 3], x[2 * g], d0);
+        d1 = MFMA16(w[g >> 2][g & 3], x[2 * g + 1], d1);
+    }
+}
+// ReLU of both D tiles (the VALU step between the MFMAs and the swap), then the swap: e0[r] / e1[r] of lane (j, h) = output rows
+// 8h + r / 8h + 4 + r of sample j
+__device__ __forceinline__ void finish16(const f32x4& d0, const f32x4& d1, float e0[4], float e1[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e0[r] = relu1(d0[r]); e1[r] = relu1(d1[r]); }
+    swap16_4(e0[0], e1[0], e0[1], e1[1], e0[2], e1[2], e0[3], e1[3]);
+}
+
+// This lane's B-operand registers of one staged view: the 19-vector feat (+) rgb in accumulator layout (register 4s+e
+// carries channel 8s + 4h + e) - where half 1 of registers 8..11 (channels 20..23: none) carries dir 0..3, the form the
+// weight.0 tail chain takes (the chains on g_v have zero weights in those slots; half 0's register 11, channel 19, reads
+// dir 0 and meets a zero weight everywhere) - and the two direction steps of view_fc (step s carries dir 2s + h).
 struct Tail32 { float fv[12]; float d[2]; };
+template <bool WITH_D>
 __device__ __forceinline__ Tail32 load_tail32(const float* __restrict__ st, int j, int h) {
     Tail32 t;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int ch = 8 * s + 4 * h + e;
-            t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
-        }
-    t.d[0] = st[(ROW_DIR + h) * 32 + j];
-    t.d[1] = st[(ROW_DIR + 2 + h) * 32 + j];
+        for (int e = 0; e < 4; ++e) t.fv[4 * s + e] = st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j];
+    const float* st2 = st + h * ((ROW_DIR - (ROW_FEAT + 16)) * 32);  // half 0: channels 16, 17, 18, (dir 0); half 1: dir 0..3
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t.fv[8 + e] = st2[(ROW_FEAT + 16 + e) * 32 + j];
+    if (WITH_D) {
+        t.d[0] = st[(ROW_DIR + h) * 32 + j];
+        t.d[1] = st[(ROW_DIR + 2 + h) * 32 + j];
+    } else t.d[0] = t.d[1] = 0.f;
     return t;
 }
-// g_v = feat ⊕ rgb + ReLU(view_fc(dir)), registers 0..11 (accumulator layout)   nerf.py:69-71
+// g_v = feat (+) rgb + ReLU(view_fc(dir)), registers 0..11 (accumulator layout)   nerf.py:69-71
+// (view_fc's rows 19..31 are zero with a zero bias, so the slots that do not carry a channel pass through unchanged)
 __device__ __forceinline__ void view_g32(const Tail32& t, const f32x4 q_view, const f32x16& b_view, float g[12]) {
     f32x16 a = MFMA32(q_view[0], t.d[0], b_view);
     a = MFMA32(q_view[1], t.d[1], a);
@@ -1048,11 +1136,10 @@ __device__ __forceinline__ void view_g32(const Tail32& t, const f32x4 q_view, co
 }
 
 // Same contract as slot_mlp_core.  `m32` = f32-MFMA section of the packed weights (global memory, L2-resident).
-// The matrix pipe is the bound here (316 MFMAs x 64 cycles per slot at V = 3), so the weight stream must never make it wait:
-// as in the f16 core every phase first issues the loads of the NEXT phase's quads and bias tables — they fly under this phase's
-// MFMA chain — and then computes with operands loaded a phase earlier (un-contended MLP time per slot 35.4k -> see DESIGN §4.1c;
-// the phases' own loads at their start had each exposed one L2 round trip: 5.9k of the 15.1k cycles of the dense middle section).
-// How much is prefetched is set by the 168-register budget of three waves per SIMD.
+// The matrix pipe is the bound here (276 MFMA-equivalents x 64 cycles per slot at V = 3), so the weight stream must never make
+// it wait: as in the f16 core every phase first issues the loads of the NEXT phase's quads and bias tables — they fly under this
+// phase's MFMA chain — and then computes with operands loaded a phase earlier.  How much is prefetched is set by the
+// 168-register budget of three waves per SIMD.
 __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float* __restrict__ m32, const float* stage, const float vox[4], int lane,
                                                   int j, int h, float b_agg, float b_w2, unsigned* dbg, float bacc[16], float fhv[4], float& sig) {
     const int V = f.V;
@@ -1061,51 +1148,54 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     f32x4 q_view;
     f32x16 b_view;
     f32x4 wg[3];
-    {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+    {   LANE_KEYS();  // mean / unbiased variance of g_v over views   nerf.py:73
         q_view = load_quad(m32, Q_VIEW, lane_o);
         b_view = load_tab(m32, T32_VIEW, h_o);
-        f32x4 wv[3], wm[3];
+        f32x4 wv[3], wm[2];
         load_quads<12>(m32, Q_GVAR, lane_o, wv);
-        load_quads<12>(m32, Q_GMEAN, lane_o, wm);
+        load_quads<8>(m32, Q_GMEAN, lane_o, wm);
         base = load_tab(m32, T32_GLOB, h_o);
         load_quads<12>(m32, Q_GA, lane_o, wg);  // next phase
-        float mean[12], m2[12];
+        // sum and sum of squares: var = (sum g^2 - V mean^2) / (V - 1).  (Welford's update costs four instructions per value
+        // and view against two; with g = O(1) the cancellation stays at the 1e-7 level of the operands.)
+        float s1[12], s2[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
+        for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            const Tail32 tl = load_tail32(stage + (size_t)v * STAGE_V, j, h);
+            const Tail32 tl = load_tail32<true>(stage + (size_t)v * STAGE_V, j, h);
             float g[12];
             view_g32(tl, q_view, b_view, g);
-            float inv = frcp((float)(v + 1));
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                float d = g[i] - mean[i];
-                mean[i] = fmaf(d, inv, mean[i]);
-                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
-            }
+            for (int i = 0; i < 12; ++i) { s1[i] += g[i]; s2[i] = fmaf(g[i], g[i], s2[i]); }
         }
-        float iv = frcp((float)(V - 1));
+        const float rv = frcp((float)V), iv = frcp((float)(V - 1));
+        float mean[12], m2[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) m2[i] = m2[i] * iv;
+        for (int i = 0; i < 12; ++i) { mean[i] = s1[i] * rv; m2[i] = (s2[i] - s1[i] * mean[i]) * iv; }
+        // mean channels 16..18 (half 0 of registers 8..10) move into half 1 of the variance registers 8..10, whose own
+        // channels (20..22) do not exist: the mean chain then needs 8 steps instead of 12
+        swap32_3(m2[8], mean[8], m2[9], mean[9], m2[10], mean[10]);
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
         base = chain32w<12>(wv, m2, base);
-        base = chain32w<12>(wm, mean, base);
+        base = chain32w<8>(wm, mean, base);
     }
     PHASE_FENCE();
     STAMP(3);
     float agg[16];
-    f32x4 wfc[4];
+    f32x4 wfc[2];
+    f32x4 bfc;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
         const f32x16 w_agg = load_tab(m32, T32_AGG, h_o);
-        load_quads<16>(m32, Q_FC, lane_o, wfc);  // next phase: fc (its bias is added after the chain: no register to park it here)
+        load_quads<8>(m32, Q_FC, lane_o, wfc);  // next phase: fc
+        bfc = load_tab16(m32, T16_FC, lane_o);
 #pragma unroll
         for (int i = 0; i < 16; ++i) agg[i] = 0.f;
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
             float g[12];
-            view_g32(load_tail32(stage + (size_t)v * STAGE_V, j, h), q_view, b_view, g);
+            view_g32(load_tail32<true>(stage + (size_t)v * STAGE_V, j, h), q_view, b_view, g);
             const f32x16 G = chain32w<12>(wg, g, base);
             float sp = dot16_relu(G, w_agg);
             float sv = relu1(sp + __shfl_xor(sp, 32) + b_agg);  // nerf.py:79
@@ -1124,40 +1214,27 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     float hb[12];  // [vox | im] operand: steps 0..7 = ReLU(im) registers 0..7, steps 8..11 = vox
     f32x4 wl0[3], wl1[3];
     f32x16 x0, x1;
-    {   LANE_KEYS();  // im = ReLU(fc(agg))   nerf.py:82
-        f32x16 im;
+    {   LANE_KEYS();  // im = ReLU(fc(agg))   nerf.py:82, on the 16-row MFMA
         load_quads<12>(m32, Q_LR0, lane_o, wl0); load_quads<12>(m32, Q_LR0 + 3, lane_o, wl1);  // next phase: lr0
         x0 = load_tab(m32, T32_LR0, h_o); x1 = load_tab(m32, T32_LR0 + 32, h_o);
-        const f32x16 bfc = load_tab(m32, T32_FC, h_o);  // lands under the chain below
-        im = chain32w<16>(wfc, agg, zero16());
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hb[i] = relu1(im[i] + bfc[i]);
+        f32x4 d0 = bfc, d1 = bfc;
+        chain16<8>(wfc, agg, d0, d1);
+        finish16(d0, d1, hb, hb + 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) hb[8 + i] = vox[i];
     }
     PHASE_FENCE();
     STAMP(4);
     float X[32];  // x = ReLU(lr0([vox | im])): [tile][register]   nerf.py:100-101
-    f32x4 wfh[8];
-    f32x16 fh;
+    f32x4 wa[8], wb[3];
+    f32x16 hs0, hs1;
     {   LANE_KEYS();
-        load_quads<32>(m32, Q_FH, lane_o, wfh);  // next phase: feat_head + sigma
-        fh = load_tab(m32, T32_FH, h_o);
+        load_quads<32>(m32, Q_W0A, lane_o, wa); load_quads<12>(m32, Q_W0B, lane_o, wb);  // next phase: weight.0 rows 0..31
+        hs0 = load_tab(m32, T32_W0, h_o);
         x0 = chain32w<12>(wl0, hb, x0);
         x1 = chain32w<12>(wl1, hb, x1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { X[i] = relu1(x0[i]); X[16 + i] = relu1(x1[i]); }
-    }
-    PHASE_FENCE();
-    f32x4 wa[8], wb[3];
-    f32x16 hs0, hs1;
-    {   LANE_KEYS();  // rows 0..7 feat_head (nerf.py:112), row 8 sigma pre-activation (:102)
-        load_quads<32>(m32, Q_W0A, lane_o, wa); load_quads<12>(m32, Q_W0B, lane_o, wb);  // next phase: weight.0 rows 0..31
-        hs0 = load_tab(m32, T32_W0, h_o);
-        fh = chain32w<32>(wfh, X, fh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fhv[i] = relu1(fh[i]);
-        sig = fh[4];
     }
     PHASE_FENCE();
     // shared part of weight.0: bias + columns on x and on [vox | im]   nerf.py:106-109
@@ -1169,15 +1246,27 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         hs0 = chain32w<12>(wb, hb, hs0);
     }
     PHASE_FENCE();
-    f32x4 wc0[4];  // per-view blend pass operands: loop-invariant, loaded once per slot
-    f32x16 w20;
+    f32x4 wfh[4];
+    f32x4 bfh;
     {   LANE_KEYS();
         load_quads<8>(m32, Q_W0A + 14, lane_o, wa2 + 6);
         load_quads<12>(m32, Q_W0B + 3, lane_o, wb);
-        load_quads<14>(m32, Q_W0C, lane_o, wc0);  // next phase
-        w20 = load_tab(m32, T32_W2, h_o);
+        load_quads<16>(m32, Q_FH, lane_o, wfh);  // next phase: feat_head + sigma
+        bfh = load_tab16(m32, T16_FH, lane_o);
         hs1 = chain32w<32>(wa2, X, hs1);
         hs1 = chain32w<12>(wb, hb, hs1);
+    }
+    PHASE_FENCE();
+    f32x4 wc0[3];  // per-view blend pass operands: loop-invariant, loaded once per slot
+    f32x16 w20;
+    {   LANE_KEYS();  // feat_head (nerf.py:112) and the sigma pre-activation (:102) on the 16-row MFMA; x is dead afterwards
+        load_quads<12>(m32, Q_W0C, lane_o, wc0);  // next phase
+        w20 = load_tab(m32, T32_W2, h_o);
+        f32x4 d0 = bfh, d1 = bfh;
+        chain16<16>(wfh, X, d0, d1);
+        float e1[4];
+        finish16(d0, d1, fhv, e1);
+        sig = e1[0] - e1[1];  // rows 4 / 5 = +s / -s (half 0): ReLU(s) - ReLU(-s) = s
     }
     PHASE_FENCE();
     STAMP(5);
@@ -1186,20 +1275,16 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
     {
         LANE_KEYS();
-        f32x4 wc1[4];
-        load_quads<14>(m32, Q_W0C + 4, lane_o, wc1);
+        f32x4 wc1[3];
+        load_quads<12>(m32, Q_W0C + 3, lane_o, wc1);
         const f32x16 w21 = load_tab(m32, T32_W2 + 32, h_o);
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
             const float* st = stage + (size_t)v * STAGE_V;
-            const Tail32 t = load_tail32(st, j, h);
-            float tb[14];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) tb[i] = t.fv[i];
-            tb[12] = t.d[0]; tb[13] = t.d[1];
-            float up = dot16_relu(chain32w<14>(wc0, tb, hs0), w20);
-            up += dot16_relu(chain32w<14>(wc1, tb, hs1), w21);
+            const Tail32 t = load_tail32<false>(st, j, h);
+            float up = dot16_relu(chain32w<12>(wc0, t.fv, hs0), w20);
+            up += dot16_relu(chain32w<12>(wc1, t.fv, hs1), w21);
             float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
             float mn = fmaxf(mx, uv);
             float sc_old = __expf(mx - mn), e = __expf(uv - mn);

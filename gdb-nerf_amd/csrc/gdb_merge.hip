@@ -10,6 +10,7 @@ int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs);
 
 struct MergeArgs {
     int B, H, W, b, Q, rew;
+    int ld, ms;  // floats between consecutive bundle rows of bf; between consecutive entries of the depth / opacity maps
     const float* bf; const float* rgb_c; const float* dep; const float* opa;
     float* img; float* odep; float* oopa;
 };
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256) k_merge(MergeArgs a) {
     const int ch = t % 3, bu = t / 3;
     const int x = bu % a.W, y = (bu / a.W) % a.H, bi = bu / (a.W * a.H);
     const int Ho = a.H * BS, Wo = a.W * BS;
-    const float* row = a.bf + (size_t)bu * a.Q + ch * BS * BS;  // channel ch*b^2 + dy*b + dx   (pixel_shuffle)
+    const float* row = a.bf + (size_t)bu * a.ld + ch * BS * BS;  // channel ch*b^2 + dy*b + dx   (pixel_shuffle)
 #pragma unroll
     for (int dy = 0; dy < BS; ++dy) {
         const RowV<BS> f = *(const RowV<BS>*)(row + dy * BS);
@@ -68,14 +69,14 @@ __global__ void __launch_bounds__(256) k_merge(MergeArgs a) {
             up_taps(x * BS + dx, a.W, inv_b, x0, x1, lx0, lx1);
             const size_t i00 = base + (size_t)y0 * a.W + x0, i01 = base + (size_t)y0 * a.W + x1;
             const size_t i10 = base + (size_t)y1 * a.W + x0, i11 = base + (size_t)y1 * a.W + x1;
-            v.v[dx] = ly0 * (lx0 * src[i00] + lx1 * src[i01]) + ly1 * (lx0 * src[i10] + lx1 * src[i11]);
+            v.v[dx] = ly0 * (lx0 * src[i00 * a.ms] + lx1 * src[i01 * a.ms]) + ly1 * (lx0 * src[i10 * a.ms] + lx1 * src[i11 * a.ms]);
         }
         *(RowV<BS>*)(dst + ((size_t)bi * Ho + (size_t)y * BS + dy) * Wo + (size_t)x * BS) = v;
     }
 }
 
-extern "C" int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const float* bf, const float* rgb_c, const float* dep, const float* opa,
-                         int32_t reweighting, float* img, float* out_dep, float* out_opa, void* stream_) {
+static int merge_entry(const GdbConfig* cfg, const GdbFrame* shape, const float* bf, int ld, const float* rgb_c, const float* dep, const float* opa,
+                       int ms, int32_t reweighting, float* img, float* out_dep, float* out_opa, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
     if (!bf || !img) return gdb_fail(GDB_E_BADARG, "NULL pointer");
@@ -83,6 +84,7 @@ extern "C" int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const floa
     MergeArgs a;
     a.B = shape->B; a.H = shape->H; a.W = shape->W; a.b = cfg->bundle_size; a.rew = reweighting != 0;
     a.Q = 3 * a.b * a.b + cfg->feat_dim + 3 + cfg->voxel_dim;
+    a.ld = ld > 0 ? ld : a.Q; a.ms = ms;
     a.bf = bf; a.rgb_c = rgb_c; a.dep = dep; a.opa = opa; a.img = img; a.odep = out_dep; a.oopa = out_opa;
     const int n = a.B * a.H * a.W;
     if (n == 0) return GDB_OK;
@@ -94,4 +96,18 @@ extern "C" int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const floa
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_merge: %s", hipGetErrorString(e));
     return GDB_OK;
+}
+
+extern "C" int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const float* bf, const float* rgb_c, const float* dep, const float* opa,
+                         int32_t reweighting, float* img, float* out_dep, float* out_opa, void* stream_) {
+    return merge_entry(cfg, shape, bf, 0, rgb_c, dep, opa, 1, reweighting, img, out_dep, out_opa, stream_);
+}
+
+// The same on the PACKED render (gdb_render_bundles_packed: rows [feat Q | depth | opacity]) read in place: what a row-strip
+// all-gather leaves on every rank, and what Network.forward renders into.
+extern "C" int gdb_merge_packed(const GdbConfig* cfg, const GdbFrame* shape, const float* packed, const float* rgb_c, int32_t reweighting,
+                                float* img, float* out_dep, float* out_opa, void* stream_) {
+    if (!cfg || !packed) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    const int Q = 3 * cfg->bundle_size * cfg->bundle_size + cfg->feat_dim + 3 + cfg->voxel_dim;
+    return merge_entry(cfg, shape, packed, Q + 2, rgb_c, packed + Q, packed + Q + 1, Q + 2, reweighting, img, out_dep, out_opa, stream_);
 }

@@ -63,7 +63,12 @@ def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32) -> torch.T
 
 
 class HotPathEngine:
-    """One engine per (config, device).  Not thread-safe: one frame in flight per engine."""
+    """One engine per (config, device).  Not thread-safe: one frame in flight per engine.
+
+    Output buffers: by default every call returns fresh tensors.  With `reuse_outputs = True` (what `Network.forward` sets:
+    `nerf.reuse_outputs`, default on) the tensors `render`, `render_packed`, `decode` and `merge` return when no `out` is passed
+    are per-engine buffers, allocated once per shape and OVERWRITTEN by the next call of the same method — no allocation and no
+    memset in the per-frame path (every element is written by the kernels).  Clone what must outlive the next frame."""
 
     def __init__(self, *, bundle_size: int = 2, max_num_samples: int = 3, is_adaptive: bool = True,
                  inv_depth: bool = False, global_num_depth: int = 64, max_mipmap_level: int = 3,
@@ -83,6 +88,23 @@ class HotPathEngine:
         self._ws: Optional[torch.Tensor] = None
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
+        self.reuse_outputs = False
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self.mip_levels: Optional[int] = None  # levels built beyond level 0 by the last prepare()
+        self._warned_levels = False
+
+    def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """Per-engine output buffer (see the class docstring); a fresh uninitialised tensor when reuse is off."""
+        shape = tuple(int(x) for x in shape)
+        if not self.reuse_outputs:
+            return torch.empty(shape, dtype=dtype, device=self.device)  # (no zero-fill either: the kernels write every element)
+        key = (name, shape, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            for k in [k for k in self._bufs if k[0] == name]:  # one shape per name: a new frame size drops the old buffer
+                del self._bufs[k]
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
+        return t
 
     # ---- derived sizes -------------------------------------------------------------------
     @property
@@ -128,10 +150,12 @@ class HotPathEngine:
 
     # ---- per-frame preparation -----------------------------------------------------------
     @_on_device
-    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None) -> None:
+    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None) -> Optional[int]:
         """Validate shapes on the host, then build the camera block and the feature pyramid.  A frame
         without the source side (only tar_ext, tar_int, near_far [, depth_range, vol_range]; pass
-        `im_size=(Ho,Wo)`) prepares the target camera alone — enough for build_rays / sample."""
+        `im_size=(Ho,Wo)`) prepares the target camera alone — enough for build_rays / sample.
+        Returns the number of mip levels built beyond level 0 (None without the source side); it is below
+        `max_mipmap_level` when an extent of the feature map turns odd on the way down (warned once)."""
         b = self.b
         if "src_images" in frame:
             si = frame["src_images"]
@@ -165,10 +189,21 @@ class HotPathEngine:
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         self._frame, self._keep = f, dict(frame)
+        if "src_images" in frame:
+            lay = (C.c_size_t * 7)()
+            _lib.check(self.lib.gdb_pyramid_layout(C.byref(self.cfg), C.byref(f), lay))
+            self.mip_levels = int(lay[2])
+            if self.mip_levels < min(self.cfg.max_mipmap_level, 3) and not self._warned_levels:
+                import warnings
+                self._warned_levels = True
+                # DESIGN.md §2, "odd-extent rule": a level is built only while both extents of the one below are even and >= 2
+                warnings.warn(f"feature map {H}x{W}: the mip chain stops at level {self.mip_levels} (an extent turns odd), below "
+                              f"nerf.max_mipmap_level = {self.cfg.max_mipmap_level}; footprints are clamped to that level")
         if fpn is not None:
             _lib.check(self.lib.gdb_prepare_fpn(C.byref(self.cfg), C.byref(f), fpn.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._stream()))
         else:
             _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        return self.mip_levels
 
     # ---- next row N1: merge around the decoder ------------------------------------------------
     @_on_device
@@ -181,18 +216,34 @@ class HotPathEngine:
         _chk(bundle_feat, "bundle_feat", (nb, self.Q))
         if rgb_c is not None:
             _chk(rgb_c, "rgb_c", (f.B, 3, Ho, Wo))
-        img = torch.empty((f.B, 3, Ho, Wo), device=self.device)
+        img = self._buf("merge.img", (f.B, 3, Ho, Wo))
         outs = []
         for name, m in (("bundle_depth", bundle_depth), ("bundle_opacity", bundle_opacity)):
             if m is not None:
                 _chk(m, name, (nb,))
-                outs.append(torch.empty((f.B, Ho, Wo), device=self.device))
+                outs.append(self._buf("merge." + name, (f.B, Ho, Wo)))
             else:
                 outs.append(None)
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self.lib.gdb_merge(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), p(rgb_c), p(bundle_depth), p(bundle_opacity),
                                       int(bool(reweighting)), img.data_ptr(), p(outs[0]), p(outs[1]), self._stream()))
         return img, outs[0], outs[1]
+
+    @_on_device
+    def merge_packed(self, packed: torch.Tensor, rgb_c: Optional[torch.Tensor] = None, reweighting: bool = False):
+        """`merge` on the packed render ((n_bundles, Q + 2) rows [bundle_feat | depth | opacity], read in place): the buffer
+        `render_packed` fills and a row-strip all-gather (parallel.StripGather) leaves on every rank.
+        Returns (img (B,3,Ho,Wo), depth (B,Ho,Wo), opacity (B,Ho,Wo))."""
+        f = self._need_frame()
+        nb, b = self.n_bundles, self.cfg.bundle_size
+        Ho, Wo = f.H * b, f.W * b
+        _chk(packed, "packed", (nb, self.Q + 2))
+        if rgb_c is not None:
+            _chk(rgb_c, "rgb_c", (f.B, 3, Ho, Wo))
+        img, dep, opa = self._buf("merge.img", (f.B, 3, Ho, Wo)), self._buf("merge.bundle_depth", (f.B, Ho, Wo)), self._buf("merge.bundle_opacity", (f.B, Ho, Wo))
+        _lib.check(self.lib.gdb_merge_packed(C.byref(self.cfg), C.byref(f), packed.data_ptr(), _ptr(rgb_c), int(bool(reweighting)),
+                                             img.data_ptr(), dep.data_ptr(), opa.data_ptr(), self._stream()))
+        return img, dep, opa
 
     # ---- next row N1: the decoder -----------------------------------------------------------------
     def load_decoder_weights(self, state: Dict[str, "torch.Tensor | np.ndarray"], num_layers: int, prefix: str = "") -> None:
@@ -237,7 +288,7 @@ class HotPathEngine:
         if getattr(self, "_dec_ws", None) is None or self._dec_ws.numel() < need.value:
             self._dec_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         b = self.cfg.bundle_size
-        rgb_c = torch.empty((f.B, 3, f.H * b, f.W * b), device=self.device)
+        rgb_c = self._buf("decode.rgb_c", (f.B, 3, f.H * b, f.W * b))
         _lib.check(self.lib.gdb_decode(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), int(bundle_feat.shape[1]), self.dec_weights.data_ptr(),
                                        self.dec_layers, int(precision), self._dec_ws.data_ptr(), self._dec_ws.numel(), rgb_c.data_ptr(), self._stream()))
         return rgb_c
@@ -409,8 +460,11 @@ class HotPathEngine:
         precision = self.precision if precision is None else precision
         nb = self.n_bundles
         if out is None:
-            out = (torch.zeros((nb, self.Q), device=self.device), torch.zeros((nb,), device=self.device),
-                   torch.zeros((nb,), device=self.device))
+            if row_begin == 0 and row_end == f.H:  # every row is written: a reused buffer needs no zero-fill
+                out = (self._buf("render.bf", (nb, self.Q)), self._buf("render.depth", (nb,)), self._buf("render.opac", (nb,)))
+            else:  # a strip into fresh tensors: rows outside it read as zeros
+                out = (torch.zeros((nb, self.Q), device=self.device), torch.zeros((nb,), device=self.device),
+                       torch.zeros((nb,), device=self.device))
         bf, depth, opac = out
         _chk(bf, "bundle_feat", (nb, self.Q)); _chk(depth, "depth", (nb,)); _chk(opac, "opacity", (nb,))
         _lib.check(self.lib.gdb_render_bundles_fused(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
@@ -422,7 +476,8 @@ class HotPathEngine:
     def render_packed(self, row_begin: int = 0, row_end: Optional[int] = None, precision: Optional[int] = None,
                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The same into ONE (n_bundles, Q + 2) tensor, row = [bundle_feat | depth | opacity]: a row strip is one contiguous
-        block, which makes the multi-GPU exchange a single all-gather (parallel.gather_packed)."""
+        block, which makes the multi-GPU exchange a single all-gather (parallel.StripGather: render the rank's strip straight
+        into `StripGather.full`, then `gather()`)."""
         if self.weights is None:
             raise ValueError("load_weights() first")
         f = self._need_frame()
@@ -430,7 +485,8 @@ class HotPathEngine:
         precision = self.precision if precision is None else precision
         nb = self.n_bundles
         if out is None:
-            out = torch.zeros((nb, self.Q + 2), device=self.device)
+            full = row_begin == 0 and row_end == f.H
+            out = self._buf("render.packed", (nb, self.Q + 2)) if full else torch.zeros((nb, self.Q + 2), device=self.device)
         _chk(out, "out", (nb, self.Q + 2))
         _lib.check(self.lib.gdb_render_bundles_packed(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
                                                       int(row_begin), int(row_end), int(precision), int(self.schedule),

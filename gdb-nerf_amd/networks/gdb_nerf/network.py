@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...engine import HotPathEngine
+from ...parallel import StripGather, gather_strips
 from . import utils
 from .bundle_sampler import BundleSampler
 from .decoder_rdn import Decoder
@@ -53,10 +54,22 @@ class Network(nn.Module):
         # "f32x" (split-f16 operand pairs: fp32-grade at close to the f16 rate)
         self.precision = {"f32": 1, "f16": 0, "f32x": 2}[str(getattr(nrf, "precision", "f32"))]
         # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
-        # False keeps the PyTorch-ROCm module.  bundle_size 2 only (one up stage).
-        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2
+        # False keeps the PyTorch-ROCm module.  The HIP decoder is built for bundle_size 2 (one up stage) and 1..3 dense blocks:
+        # any other shape keeps the PyTorch module, as before.
+        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2 and 1 <= int(self.dec_layers) <= 3
+        # Multi-GPU: "rows" = when torch.distributed is initialised, every rank renders one contiguous strip of
+        # bundle-map rows of the frame and ONE all-gather of the packed rows (RCCL over xGMI) leaves the whole bundle map on every
+        # rank; decoder and merge then run replicated (the decoder's squeeze-excitation takes a global mean over the image,
+        # decoder_rdn.py:10,20, so it does not shard by rows).  "none" (default): every rank renders whole frames.
+        self.shard = str(getattr(nrf, "shard", "none"))
+        if self.shard not in ("none", "rows"):
+            raise ValueError(f"nerf.shard must be 'none' or 'rows', got {self.shard!r}")
+        # per-engine output buffers reused frame after frame (no allocation / memset in the per-frame path): the tensors in the
+        # returned dict are overwritten by the next forward; False returns fresh tensors
+        self.reuse_outputs = bool(getattr(nrf, "reuse_outputs", True))
         self._feat_dim = feat_dim
         self._engine = None
+        self._gather = None
 
     # ---- hot path ------------------------------------------------------------------------
     def _get_engine(self, device) -> HotPathEngine:
@@ -66,13 +79,55 @@ class Network(nn.Module):
                                          max_mipmap_level=self.max_mipmap_level, feat_dim=self._feat_dim, voxel_dim=self.voxel_dim,
                                          hid_dim=self.nerf_hidden_dims, viewdir_agg=self.viewdir_agg, device=device)
         self._engine.precision = self.precision
+        self._engine.reuse_outputs = self.reuse_outputs
         self.nerf.sync_engine(self._engine)
         if self.hip_decoder:
-            v = tuple(p._version for p in self.upsampler.parameters())
+            # (storage, version) per tensor, as NeRF.param_versions: `p.data = ...` and load_state_dict(assign=True) change the
+            # storage without touching the version counter.  (`p.data.copy_()` changes neither: call invalidate_packed_weights().)
+            v = tuple((p.data_ptr(), p._version) for p in self.upsampler.parameters())
             if getattr(self._engine, "_dec_versions", None) != v:
                 self._engine.load_decoder_weights({k: t.detach() for k, t in self.upsampler.state_dict().items()}, self.dec_layers)
                 self._engine._dec_versions = v
         return self._engine
+
+    def invalidate_packed_weights(self) -> None:
+        """Force a re-pack of the NeRF and decoder weights on the next forward (needed only after an in-place write through
+        `.data`, which PyTorch does not version)."""
+        if self._engine is not None:
+            self._engine._dec_versions = None
+            self._engine._nerf_versions = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed_weights()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _dist(self):
+        """torch.distributed when this forward is to be row-sharded, else None."""
+        if self.shard != "rows":
+            return None
+        import torch.distributed as dist
+        return dist if dist.is_available() and dist.is_initialized() else None
+
+    def _render_packed(self, eng, B: int, H: int, W: int) -> torch.Tensor:
+        """The hot path of the prepared frame into packed rows [bundle_feat | depth | opacity] (n_bundles, Q + 2); row-sharded over
+        the ranks of the default process group when `nerf.shard: rows` (reference call site network.py:145-169; the eval loop
+        run.py:54-66 calls this once per frame on every rank)."""
+        dist = self._dist()
+        if dist is None:
+            return eng.render_packed()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        C = eng.Q + 2
+        if B == 1:  # one contiguous strip per rank: in-place all-gather, buffers cached per shape
+            g = self._gather
+            if g is None or (g.H, g.W, g.C, g.world, g.rank) != (H, W, C, world, rank) or g.full.device != eng.device:
+                g = self._gather = StripGather(H, W, C, world, rank, eng.device, dist)
+            r0, r1 = g.strip
+            eng.render_packed(r0, r1, None, g.full)
+            return g.gather()
+        from ...parallel import row_strip
+        r0, r1 = row_strip(H, rank, world)
+        full = eng.render_packed(r0, r1)  # fresh, zero-filled outside the strip
+        return gather_strips(full, H, world, dist, B=B)
 
     def render_bundles(self, rgbs_feat_rgb_dir, vox_feat, z_vals, indices, samples_per_bundle):
         """MLP + normalised alpha composite on materialised samples (reference network.py:54-91)."""
@@ -124,7 +179,14 @@ class Network(nn.Module):
             eng.prepare({"src_images": c(src_images), "fpn_feat": c(img_feat), "feat_volume": c(feat_volume),
                          "depth_range": c(depth_range), "vol_range": c(vol_range), "src_exts": c(src_exts), "src_ints": c(src_ints),
                          "tar_ext": c(tar_exts), "tar_int": c(tar_ints), "near_far": c(near_far)})
-            bundle_feat, bundle_depth, bundle_opacity = eng.render()
+            packed = self._render_packed(eng, B, H, W)
+            if self.hip_decoder:
+                rgb_c = eng.decode(packed)   # reads channels 3 b^2 .. Q-1 of the packed rows in place
+            else:
+                rgb_c = self.upsampler(packed[:, 3 * b * b:eng.Q].view(B, H, W, -1).permute(0, 3, 1, 2)).contiguous().float()
+            # N1: pixel-shuffle + add (+ re-weighting) + the two x b upsamplings in one HIP kernel, on the packed rows in place
+            img, nerf_depth, opacity = eng.merge_packed(packed, rgb_c, self.reweighting)
+            return {"rgb": img, "nerf_depth": nerf_depth, "mvs_depth": mvs_depth, "opacity": opacity}, mvs_depths, blend_rgbs
         else:
             rgb_lo = F.interpolate(src_images.flatten(0, 1), size=(H, W), mode="bilinear", align_corners=False).unflatten(0, (B, V))
             img_feat_rgb = torch.cat((img_feat, rgb_lo), dim=2)
@@ -136,13 +198,7 @@ class Network(nn.Module):
 
         nerf_feat = bundle_feat.view(B, H, W, -1).permute(0, 3, 1, 2)
         n_rgb = 3 * b * b
-        if eng is not None and self.hip_decoder:
-            rgb_c = eng.decode(bundle_feat)   # reads channels n_rgb.. of the bundle rows in place
-        else:
-            rgb_c = self.upsampler(nerf_feat[:, n_rgb:])
-        if eng is not None:  # N1: pixel-shuffle + add (+ re-weighting) + the two x b upsamplings in one HIP kernel
-            img, nerf_depth, opacity = eng.merge(bundle_feat, rgb_c.contiguous().float(), bundle_depth, bundle_opacity, self.reweighting)
-            return {"rgb": img, "nerf_depth": nerf_depth, "mvs_depth": mvs_depth, "opacity": opacity}, mvs_depths, blend_rgbs
+        rgb_c = self.upsampler(nerf_feat[:, n_rgb:])
         rgb_f = F.pixel_shuffle(nerf_feat[:, :n_rgb], b)
         up = lambda t: F.interpolate(t.view(B, 1, H, W), scale_factor=b, mode="bilinear", align_corners=False).squeeze(1)
         img = rgb_c + rgb_f

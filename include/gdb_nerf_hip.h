@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 3
+#define GDB_ABI_VERSION 4
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -256,6 +256,10 @@ int gdb_depth_regression(const float* d_depth_values, const float* d_depth_prob,
 int gdb_merge(const GdbConfig* cfg, const GdbFrame* shape, const float* d_bundle_feat, const float* d_rgb_c,
               const float* d_bundle_depth, const float* d_bundle_opacity, int32_t reweighting, float* d_img,
               float* d_out_depth, float* d_out_opacity, void* stream);
+/* The same on the packed render of gdb_render_bundles_packed ((n_bundles, Q + 2) rows [bundle_feat | depth | opacity]), read in
+ * place: the buffer a row-strip all-gather leaves on every rank (network.py:170-182 after the exchange of SURVEY.md 8(e)). */
+int gdb_merge_packed(const GdbConfig* cfg, const GdbFrame* shape, const float* d_packed, const float* d_rgb_c, int32_t reweighting,
+                     float* d_img, float* d_out_depth, float* d_out_opacity, void* stream);
 
 /* ---- the decoder itself (next row N1) --------------------------------------------------- */
 /* Decoder.forward, networks/gdb_nerf/decoder_rdn.py:44-81 (instantiated at network.py:51 as Decoder(C_f+3+C_v, 3, num_feats=64,

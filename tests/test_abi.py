@@ -125,7 +125,7 @@ int main(void) {
     GdbConfig c; GdbFrame f;
     if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
     for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
-    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 3) return 12;
+    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 4) return 12;
     memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
     c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
     if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */
