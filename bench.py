@@ -419,7 +419,7 @@ def main():
     ab = alg_bytes(Ho, Wo, V) * share
     af = alg_flops(n_samples, V) * share
     if args.path == "fused":
-        auto = 3 if (wl["adaptive"] and wl["S"] > 3) else (1 if wl["S"] <= 3 else 2)   # GDB_SCHED_AUTO's rule (gdb_fused.hip render_launch)
+        auto = 3 if wl["adaptive"] else (1 if wl["S"] <= 3 else 2)   # GDB_SCHED_AUTO's rule (gdb_fused.hip render_launch)
         kname = {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense"}[args.schedule or auto]
     else:
         kname = "k_mlp"

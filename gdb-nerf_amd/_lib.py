@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.
 ABI_VERSION = 4
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
+SCHED_PLAN_READY = 0x100
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8
@@ -45,6 +46,7 @@ _SIGNATURES = {
     "gdb_workspace_bytes": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_pyramid_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_dense_plan_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
+    "gdb_dense_map_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_packed_weight_floats": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
     "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),

@@ -1615,16 +1615,85 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
 // ---------------------------------------------------------------------------------------------------------------
 // Dense schedule (GDB_SCHED_DENSE): the reference's flat, compacted sample list (bundle_sampler.py:182-189) cut into waves.
 // One wave = one window of a bundle-map row: the consecutive bundles whose first sample offset falls into [L w, L (w + 1)),
-// L = 33 - S_max, which together hold at most 32 samples (the plan, built by k_prepare, names each window's first bundle).
-// Lane (j, h): j = sample of the window (bundle-major, sample-minor, exactly the reference's order), h = half as everywhere.
-// Every lane carries a sample (but for the window's tail), where the slot schedules leave a lane idle whenever its bundle
-// has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy, c4 64 % -> 88 %.
-// The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by
-// looking back over the earlier samples, weighted sums by a segmented suffix sum in log2(S_max) shuffle steps, the bundle's
-// first lane normalises and hands the row to the LDS transpose.  utils.py:35-41, :109-119, network.py:83-89.
+// L = 33 - S_max, which together hold at most 32 samples.  The plan (plan_row: k_prepare or k_plan) names each window's first
+// bundle AND lists the row's samples in the reference's order, entry s = [bundle | slot | count]: the wave of window w reads
+// entries [L w, L w + 32) - lane j IS sample L w + j - and keeps those whose bundle starts inside the window (the first few
+// lanes may hold the tail of the previous window's last bundle: idle here, rendered there).  No per-wave count, scan or LDS map.
+// Lane (j, h): j = sample, h = half as everywhere.  Every lane carries a sample but for the window's edges, where the slot
+// schedules leave a lane idle whenever its bundle has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy,
+// c4 64 % -> 88 %.
+// The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by looking
+// back over the earlier samples, the 22 weighted sums by a segmented suffix sum - for S_max <= 4 a Horner chain of DPP
+// wave shifts (acc <- v + next(acc): two VALU instructions per value and step, no LDS crossbar), beyond that log2(S_max)
+// ds_bpermute doubling steps -, the bundle's first lane normalises and hands the row to the LDS transpose.
+// utils.py:35-41, :109-119, network.py:83-89.
 // NWG = waves per workgroup (independent windows, no workgroup barrier anywhere): LDS is allocated in 1280-byte granules, and
 // two waves' areas in one allocation can fit where single ones lose a wave per CU to the rounding (fp32 staging, V = 3: 13,440 B
 // per wave = 11 one-wave workgroups per CU, but 6 two-wave ones = 12 waves).
+// lane i <- lane i + 1 / i - 1 of the wave (0 past the ends): gfx9 DPP wave shifts
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+// The grid of the dense schedule is sized for the worst case (every bundle at S_max: planMW windows per row) but its tiles are
+// numbered densely over the windows IN USE, so every workgroup up to the last live one carries work and the surplus ones all sit
+// at the end of the grid.  (Numbered row-major over the worst-case grid the surplus windows end every row, and dead workgroups
+// between live ones kept a quarter of the wave slots empty through the whole launch: 2.4 instead of 2.9 waves per SIMD in the
+// steady state of c2, profiles/r03/dense_occupancy.txt.)  A wave turns its tile index into (row, window) with one scan of the
+// per-row window counts plan_row left (WsLayout::nwinOff) - four rows per lane, 256 rows per round - restricted to the rows
+// [rlo, rhi) this launch renders.  Everything comes out wave-uniform.  Returns false when the wave has no tile.
+template <int NWG>
+__device__ __forceinline__ bool dense_tile(const DevFrame& f, int rlo, int rhi, int lane, int wv, int& rowid, int& win) {
+    const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;  // int4s of the count array that touch the strip
+    auto counts = [&](int c0, int& s4) {  // this lane's four rows of round c0: clamped to what the grid was sized for, zero outside the strip
+        const int q = c0 + lane;
+        int4 n = make_int4(0, 0, 0, 0);
+        if (q < nq) n = ((const int4*)f.nwin)[q0 + q];
+        const int r4 = (q0 + q) << 2;
+        n.x = (r4 + 0 >= rlo && r4 + 0 < rhi) ? min(max(n.x, 0), f.planMW) : 0;
+        n.y = (r4 + 1 >= rlo && r4 + 1 < rhi) ? min(max(n.y, 0), f.planMW) : 0;
+        n.z = (r4 + 2 >= rlo && r4 + 2 < rhi) ? min(max(n.z, 0), f.planMW) : 0;
+        n.w = (r4 + 3 >= rlo && r4 + 3 < rhi) ? min(max(n.w, 0), f.planMW) : 0;
+        s4 = n.x + n.y + n.z + n.w;
+        return n;
+    };
+    auto scan = [&](int v) {  // inclusive prefix over the 64 lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d); if (lane >= d) v += u; }
+        return v;
+    };
+    int s4;
+    int4 n = counts(0, s4);
+    int incl = scan(s4);
+    int T = __shfl(incl, 63);
+    for (int c0 = 64; c0 < nq; c0 += 64) {  // strips of more than 256 rows: the total needs the later rounds too
+        int s; counts(c0, s);
+        T += __shfl(scan(s), 63);
+    }
+    // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2); each XCD gets one contiguous band of tiles
+    const int chunkd = ((T + NWG - 1) / NWG + 7) >> 3;
+    const int t = ((int)(blockIdx.x & 7) * chunkd + (int)(blockIdx.x >> 3)) * NWG + wv;
+    if ((int)(blockIdx.x >> 3) >= chunkd || t >= T) return false;
+    int run = 0;
+    for (int c0 = 0; c0 < nq; c0 += 64) {
+        if (c0) { n = counts(c0, s4); incl = scan(s4); }
+        const int tot = __shfl(incl, 63), tl = t - run;
+        if (tl < tot) {
+            const int ls = __builtin_ctzll(__ballot(tl < incl));  // the lane whose four rows hold the tile
+            const int ex = __builtin_amdgcn_readlane(incl - s4, ls);
+            const int nx = __builtin_amdgcn_readlane(n.x, ls), ny = __builtin_amdgcn_readlane(n.y, ls), nz = __builtin_amdgcn_readlane(n.z, ls);
+            int r = (q0 + c0 + ls) << 2, rem = tl - ex;
+            if (rem >= nx) { rem -= nx; ++r; if (rem >= ny) { rem -= ny; ++r; if (rem >= nz) { rem -= nz; ++r; } } }
+            rowid = r; win = rem;
+            return true;
+        }
+        run += tot;
+    }
+    return false;
+}
+
 template <int PREC, int WPS, int NWG>
 __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     const DevFrame& f = a.f;
@@ -1632,19 +1701,22 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     unsigned* dbg = a.dbg; (void)dbg;
-    const int chunk = ((a.ntiles + NWG - 1) / NWG + 7) >> 3;  // XCD-aware tile order: one contiguous band of (row, window) tiles per XCD
-    const int tile = ((blockIdx.x & 7) * chunk + (blockIdx.x >> 3)) * NWG + wv;
-    if (tile >= a.ntiles) return;
-    const int win = tile % f.planMW, rr = tile / f.planMW;
-    const int row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
-    const int* rec = f.plan + (size_t)(bi * f.H + row) * (f.planMW + 2);
-    typedef const int __attribute__((address_space(4))) kint;  // written by k_prepare, an earlier launch: scalar loads
-    const kint* krec = (const kint*)rec;
-    if (win >= krec[0]) return;  // the grid is sized for the worst case (every bundle at S_max); surplus windows leave at once
-    // this window's bundles: first .. first + nb - 1, nb <= 32.  Clamped, so that a plan that does not belong to this frame
-    // (gdb_prepare not run on it) renders garbage instead of reading outside the frame.
+    // ---- dense tile index -> (row, window) -------------------------------------------------------------------------------
+    const int bi = blockIdx.y;
+    int rowid, win;
+    if (!dense_tile<NWG>(f, bi * f.H + a.row_begin, bi * f.H + a.row_begin + a.nrows, lane, wv, rowid, win)) return;
+    rowid = __builtin_amdgcn_readfirstlane(rowid); win = __builtin_amdgcn_readfirstlane(win);
+    const int row = rowid - bi * f.H;
+    typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
+    const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
+    if (win >= krec[0]) return;  // (cannot happen with a plan that belongs to this depth prior)
+    // this window's bundles: first .. first + nb - 1, nb <= 32.  Everything read from the plan is clamped to the frame, so that a
+    // plan that does not belong to this frame's depth prior renders garbage instead of reading or writing outside the frame.
     const int first = min(max(krec[1 + win], 0), f.W - 1);
     const int nb = min(max(krec[2 + win] - first, 0), min(32, f.W - first));
+    if (nb <= 0) return;
+    const int L = f.planL, s0 = L * win;
+    const unsigned m = ldu<unsigned>(f.smap + (size_t)rowid * f.smapStride, 4u * (unsigned)(s0 + j));  // lane j = sample s0 + j of the row
     float tc[TAR_STRIDE];
     {
         const kfloat* tcg = kptr(tar_cam(f, bi));
@@ -1652,32 +1724,10 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
     STAMP(0);
-    // ---- lane j as BUNDLE first + j: its sample count and the offset of its first sample inside the window --------------
-    int cnt_b = 0;
-    if (j < nb) {
-        float r[4];
-        load_ranges(f, bi, row, first + j, r);
-        float n0 = r[0], f0 = r[1];
-        if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
-        cnt_b = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
-    }
-    int incl = cnt_b;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 32); if (j >= d) incl += t; }
-    const int total = min(__shfl(incl, 31, 32), 32);  // samples in this window (<= 32 by construction of the plan)
-    // sample -> (bundle, slot) map through LDS (the staging area is not in use yet)
-    int* smap = (int*)stage;
-    if (h == 0)
-        for (int k = 0; k < cnt_b; ++k)
-            if (incl - cnt_b + k < 32) smap[incl - cnt_b + k] = j | (k << 8);
-    __builtin_amdgcn_wave_barrier();
-    PHASE_FENCE();
-    // ---- lane j as SAMPLE j of the window -------------------------------------------------------------------------------
-    const bool act = j < total;
-    const int m = smap[act ? j : 0];
-    const int bj = m & 255, k = m >> 8;
-    __builtin_amdgcn_wave_barrier();
-    PHASE_FENCE();
+    const int mx = (int)(m & 0xFFFFu), k = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
+    const int bj = min(max(mx - first, 0), nb - 1);          // this sample's bundle inside the window (= its output column)
+    // a sample of this window: its bundle starts at an offset inside [s0, s0 + L)
+    const bool act = m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k >= 0 && j - k < L && k < mcnt && mcnt <= f.S_max;
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
     float z; float vox[4];
@@ -1685,9 +1735,9 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     {
         Bundle<4> q;
         load_bundle<4, true>(f, tc, bi, row, first + bj, q);
-        cnt = q.count;
+        cnt = q.count;  // (equals the list's count when the plan belongs to this depth prior)
         STAMP(1);
-        slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
+        slot_gather_q<PREC>(f, stage, tc, q, min(k, cnt - 1), bi, j, h, a.skip, act, z, vox);
     }
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
@@ -1705,23 +1755,52 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     }
     // ---- composite across the lanes of a bundle --------------------------------------------------------------------------
     const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
-    float Tr = 1.f;
     const int S = f.S_max;
-    for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
-        const float ap = __shfl_up(al, d, 32);
-        if (d <= k) Tr *= 1.f - ap;
-    }
-    const float w = al * Tr;
+    if (S <= 4) {
+        // An active sample's earlier samples are the lanes just below it in the same half (k <= j), a bundle's later samples the
+        // lanes just above (they end at lane 31 at the latest): whole-wave DPP shifts never carry a value across a bundle's edge
+        // that the predicates below do not mask.
+        float Tr = 1.f, ap = al;
 #pragma unroll
-    for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
-    v[20] = w;
-    v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
-    for (int d = 1; d < S; d <<= 1) {  // segmented suffix sums: afterwards the bundle's first lane (k == 0) holds the bundle's sums
-        const bool take = act && k + d < cnt;
+        for (int d = 1; d < 4; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
+            ap = wave_shr1(ap);
+            if (d <= k) Tr *= 1.f - ap;
+        }
+        const float w = al * Tr;
 #pragma unroll
-        for (int i = 0; i < 22; ++i) {
-            const float t = __shfl_down(v[i], d, 32);
-            if (take) v[i] += t;
+        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
+        v[20] = w;
+        v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
+        // Segmented suffix sums as a Horner chain: acc <- v + (the bundle has a next sample ? acc of the next lane : 0); after
+        // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.
+        const float nxt = (act && k + 1 < cnt) ? 1.f : 0.f;
+        float acc[22];
+#pragma unroll
+        for (int i = 0; i < 22; ++i) acc[i] = v[i];
+        for (int d = 1; d < S; ++d) {
+#pragma unroll
+            for (int i = 0; i < 22; ++i) acc[i] = fmaf(wave_shl1(acc[i]), nxt, v[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 22; ++i) v[i] = acc[i];
+    } else {
+        float Tr = 1.f;
+        for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
+            const float ap = __shfl_up(al, d, 32);
+            if (d <= k) Tr *= 1.f - ap;
+        }
+        const float w = al * Tr;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
+        v[20] = w;
+        v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
+        for (int d = 1; d < S; d <<= 1) {  // segmented suffix sums by doubling (ds_bpermute): the bundle's first lane ends with its sums
+            const bool take = act && k + d < cnt;
+#pragma unroll
+            for (int i = 0; i < 22; ++i) {
+                const float t = __shfl_down(v[i], d, 32);
+                if (take) v[i] += t;
+            }
         }
     }
     STAMP(7);
@@ -1799,15 +1878,15 @@ static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
         static std::atomic<unsigned long long> done2{0};
         hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 2>, done2);
         if (e != hipSuccess) return e;
-        const unsigned grid = (unsigned)(((a.ntiles + 1) / 2 + 7) / 8 * 8);
-        hipLaunchKernelGGL((k_render_dense<PREC, WPS, 2>), dim3(grid), dim3(128), 2 * lds, st, a);
+        const unsigned grid = (unsigned)(((a.ntiles + 1) / 2 + 7) / 8 * 8);  // a.ntiles: worst case per batch item; grid y = batch item
+        hipLaunchKernelGGL((k_render_dense<PREC, WPS, 2>), dim3(grid, (unsigned)a.f.B), dim3(128), 2 * lds, st, a);
         return hipGetLastError();
     }
     static std::atomic<unsigned long long> done{0};
     hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 1>, done);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_render_dense<PREC, WPS, 1>), dim3(grid), dim3(64), lds, st, a);
+    hipLaunchKernelGGL((k_render_dense<PREC, WPS, 1>), dim3(grid, (unsigned)a.f.B), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -1821,7 +1900,7 @@ static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t
 }
 
 template <int PREC>
-static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const void* ws, int sched, hipStream_t st) {
+static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const void* ws, int sched, bool plan_ready, hipStream_t st) {
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * stage_v<PREC>();
     const size_t lds_max = 160 * 1024;
@@ -1841,20 +1920,22 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     static const size_t env_pad = getenv("GDB_FUSED_LDS_PAD") ? (size_t)atol(getenv("GDB_FUSED_LDS_PAD")) : 0;
     pad = env_pad;
 #endif
-    // Dense: the compacted sample list, one wave per <= 32 consecutive samples (needs the plan gdb_prepare builds from the
-    // depth prior).  Taken for adaptive counts, where the slot schedules leave lanes idle.
-    // (measured on MI355X, profiles/r02/schedules.txt: c4, S_max 6 adaptive, 64 % of the slot lanes busy: 132 vs 158 us f16,
-    // 283 vs 397 us f32; c2, S_max 3, 80 % busy: 67 vs 59 us f16, 139 vs 133 us f32 — the slot waves stay for S_max <= 3)
-    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && S > 3);
+    // Dense: the compacted sample list, one wave per <= 32 consecutive samples (needs the plan built from the depth prior).
+    // Taken for adaptive counts, where the slot schedules leave lanes idle (c2, S_max 3: 80 % of the slot lanes busy, c4, S_max 6:
+    // 64 %).  Measured on MI355X (profiles/r03/schedules.txt), dense vs slot waves at f32: c2 103 vs 116 us, c3 183 vs 196,
+    // c3' 215 vs 240; f16 / split-f16 on c2: 56.3 vs 56.5, 70.1 vs 71.0 (round 2's dense schedule lost on c2: its per-wave
+    // count / scan / LDS-map prologue, a ds_bpermute composite, and a grid with dead workgroups between live ones).
+    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && fr->W < 65536);
     if (want_dense && solo_lds <= lds_max) {
-        // gdb_prepare builds the plan when AUTO takes this schedule; for an explicit request on other shapes it is built here,
-        // into the plan region of the caller's workspace (a launch of its own on the same stream)
-        if (!(cfg->is_adaptive && S > 3)) {
+        if (fr->W >= 65536) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles in 16 bits: W = %d >= 65536", fr->W);
+        // The plan + sample list are built here, into the plan region of the caller's workspace (a launch of its own on the same
+        // stream), unless the caller vouches that gdb_prepare built them from the depth prior as it stands (GDB_SCHED_PLAN_READY).
+        if (!plan_ready) {
             int rc = gdb_build_dense_plan(cfg, fr, const_cast<void*>(ws), st);
             if (rc) return rc;
         }
         a.alias = 0;
-        a.ntiles = fr->B * a.nrows * a.f.planMW;
+        a.ntiles = a.nrows * a.f.planMW;  // per batch item, worst case (every bundle at S_max)
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
         bool three = false;
         if constexpr (PREC != GDB_PREC_F32) three = 12 * (solo_lds + pad) <= lds_max;
@@ -1893,6 +1974,8 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
     if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X)
         return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA, 2 = split-f16 operands)", precision);
+    const bool plan_ready = (schedule & GDB_SCHED_PLAN_READY) != 0;
+    schedule &= ~GDB_SCHED_PLAN_READY;
     if (schedule < 0 || schedule > 3) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..3", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
@@ -1919,9 +2002,9 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.skip = env_skip; a.dbg = g_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream_;
-    if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, st);
-    if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, ws, schedule, st);
-    return render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, st);
+    if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, plan_ready, st);
+    if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, ws, schedule, plan_ready, st);
+    return render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, plan_ready, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,

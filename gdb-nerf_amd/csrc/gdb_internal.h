@@ -70,6 +70,10 @@ struct WsLayout {
     size_t total;
     int nBlocksScan;
     int planL, planMW;  // dense schedule: sample-offset window length, windows per bundle-map row at most (plan row = planMW + 2 ints)
+    size_t smapOff;     // dense schedule: the compacted sample list itself, one uint32 per sample offset of a row
+    int smapStride;     // entries per bundle-map row (planMW * planL + 32: a window's 32 lanes never read past it)
+    size_t nwinOff;     // dense schedule: windows in use per bundle-map row (int32 per row, padded to whole int4s): the render waves
+                        // turn a dense tile index into (row, window) with one scan of it, so the grid holds no empty windows between rows
 };
 
 #define SCAN_BLOCK 1024
@@ -104,6 +108,12 @@ static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
     L.planL = 33 - c.max_num_samples;
     L.planMW = (int)(((size_t)f.W * c.max_num_samples + L.planL - 1) / L.planL);
     L.planOff = off; off = align_up(off + sizeof(int32_t) * (size_t)f.B * f.H * (L.planMW + 2), 256);
+    // ... and the sample list of every row (bundle_sampler.py:182-189: bundle-major, sample-minor): entry s of a row names the
+    // sample at offset s = [bundle x (16 bits) | slot k (8) | the bundle's count (8)], 0xFFFFFFFF past the row's last sample.
+    // Window w's wave reads entries [planL w, planL w + 32): lane = sample, no per-wave count / scan / LDS map.
+    L.smapStride = L.planMW * L.planL + 32;
+    L.smapOff = off; off = align_up(off + sizeof(uint32_t) * (size_t)f.B * f.H * L.smapStride, 256);
+    L.nwinOff = off; off = align_up(off + sizeof(int32_t) * ((size_t)f.B * f.H + 8), 256);
     L.total = off;
     return L;
 }
@@ -118,6 +128,8 @@ struct DevFrame {
     float invW, invH;  // 1/W, 1/H of the bundle map (uniform reciprocals the fused kernel would otherwise recompute per view)
     int planL, planMW;
     const int* plan;   // dense-schedule plan rows: [nwin, first bundle of window 0..nwin-1, W]
+    const unsigned* smap; int smapStride;  // dense-schedule sample list, smapStride entries per row
+    const int* nwin;   // dense-schedule windows in use per row
     const float* cams;
     const float* pyr;
     const float* src_images;
@@ -135,6 +147,8 @@ static inline DevFrame dev_frame(const GdbConfig& c, const GdbFrame& f, const Ws
     d.invW = 1.f / (float)f.W; d.invH = 1.f / (float)f.H;
     d.planL = L.planL; d.planMW = L.planMW;
     d.plan = (const int*)((const char*)ws + L.planOff);
+    d.smap = (const unsigned*)((const char*)ws + L.smapOff); d.smapStride = L.smapStride;
+    d.nwin = (const int*)((const char*)ws + L.nwinOff);
     d.cams = (const float*)((const char*)ws + L.camsOff);
     d.pyr = (const float*)((const char*)ws + L.pyrOff);
     d.src_images = f.d_src_images; d.feat_volume = f.d_feat_volume;

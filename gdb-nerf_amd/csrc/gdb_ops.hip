@@ -91,6 +91,15 @@ extern "C" int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape
     return GDB_OK;
 }
 
+extern "C" int gdb_dense_map_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[2]) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
+    if (!out) return gdb_fail(GDB_E_BADARG, "out is NULL");
+    const WsLayout L = ws_layout(*cfg, *shape);
+    out[0] = L.smapOff; out[1] = (size_t)L.smapStride;
+    return GDB_OK;
+}
+
 extern "C" int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
@@ -205,11 +214,13 @@ struct PrepArgs {
     // dense-schedule plan: workgroups ntiles+1 .. ntiles+nplan, one wave per bundle-map row
     int nplan, S_max, adaptive, planL, planMW;
     const float* depth_range; int* plan;
+    unsigned* smap; int smapStride; int* nwin;
 };
 
 // One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, and for
 // every window of planL consecutive sample offsets the first bundle whose offset falls into it.  Row record: [number of windows,
 // first bundle of window 0 .. nwin-1, W].  Lane l takes the bundles [l * cpl, (l+1) * cpl) of the row.
+// Also the row's compacted sample list (WsLayout::smapOff): entry s = [bundle | slot << 16 | count << 24].
 __device__ void plan_row(const PrepArgs& a, int rowid, int lane) {
     const int bi = rowid / a.H, row = rowid % a.H;
     const float nr = a.near_far[bi * 2], fr = a.near_far[bi * 2 + 1];
@@ -234,16 +245,20 @@ __device__ void plan_row(const PrepArgs& a, int rowid, int lane) {
     int cprev = __shfl_up(lastc, 1);            // count of the bundle just before it
     if (lane == 0) cprev = 0;
     int* rec = a.plan + (size_t)rowid * (a.planMW + 2);
-    (void)total;
+    unsigned* sm = a.smap + (size_t)rowid * a.smapStride;
+    for (int s = total + lane; s < a.smapStride; s += 64) sm[s] = 0xFFFFFFFFu;  // past the row's last sample
     for (int x = x0; x < x1; ++x) {
         const int w = off / a.planL;
+        const int c = count_at(x);
+        // the row's sample list: bundle-major, sample-minor (bundle_sampler.py:182-189)
+        for (int k = 0; k < c; ++k) sm[off + k] = (unsigned)x | ((unsigned)k << 16) | ((unsigned)c << 24);
         // consecutive bundle offsets differ by at most S_max <= planL, so every window up to the one the LAST bundle starts in
         // has a first bundle; windows beyond that one hold no bundle start (the last bundle's samples may reach into the next
         // window of offsets — they still belong to the window the bundle starts in)
         if (x == 0 || (off - cprev) / a.planL != w) rec[1 + w] = x;
-        if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = a.W; }
-        cprev = count_at(x);
-        off += cprev;
+        if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = a.W; a.nwin[rowid] = w + 1; }
+        cprev = c;
+        off += c;
     }
 }
 
@@ -352,6 +367,7 @@ int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipS
     a.B = f->B; a.H = f->H; a.W = f->W; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
     a.near_far = f->d_near_far; a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
+    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff);
     hipLaunchKernelGGL(k_plan, dim3((f->B * f->H + 3) / 4), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_plan");
     return GDB_OK;
@@ -393,9 +409,11 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     // the dense schedule's plan needs the depth prior; a frame prepared without it (build_rays / sample only) has none
     a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
-    // Built here (inside this launch, ~1 us) when GDB_SCHED_AUTO will take the dense schedule; an explicit GDB_SCHED_DENSE on
-    // other shapes has gdb_render_bundles_* build it on demand (gdb_build_dense_plan, a launch of its own).
-    a.nplan = (f->d_depth_range && cfg->is_adaptive && cfg->max_num_samples > 3) ? (f->B * f->H + 3) / 4 : 0;
+    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff);
+    // Built here (inside this launch, ~1 us) for adaptive configs whenever the frame carries its depth prior: a render call that
+    // is told so (GDB_SCHED_PLAN_READY) uses it as it stands; any other dense render builds the plan itself (gdb_build_dense_plan,
+    // a launch of its own on the same stream).
+    a.nplan = (f->d_depth_range && cfg->is_adaptive) ? (f->B * f->H + 3) / 4 : 0;
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;

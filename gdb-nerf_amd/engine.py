@@ -86,6 +86,7 @@ class HotPathEngine:
         self._frame: Optional[GdbFrame] = None
         self._keep: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
+        self._plan_key = None
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
         self.reuse_outputs = False
@@ -189,6 +190,10 @@ class HotPathEngine:
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         self._frame, self._keep = f, dict(frame)
+        # gdb_prepare builds the dense schedule's plan from the depth prior as it is NOW (adaptive configs); a later render may
+        # skip its own rebuild (GDB_SCHED_PLAN_READY) only while that tensor is unchanged: same storage, same version counter
+        dr = frame.get("depth_range")
+        self._plan_key = (dr.data_ptr(), dr._version) if (dr is not None and self.cfg.is_adaptive) else None
         if "src_images" in frame:
             lay = (C.c_size_t * 7)()
             _lib.check(self.lib.gdb_pyramid_layout(C.byref(self.cfg), C.byref(f), lay))
@@ -328,11 +333,28 @@ class HotPathEngine:
         t.window = int(out[2])
         return t
 
+    def dense_map(self) -> torch.Tensor:
+        """The compacted sample list beside the plan: (B*H, stride) int64 (from uint32), entry s of a row = bundle | slot << 16 |
+        count << 24 of the sample at offset s, 0xFFFFFFFF past the row's last sample (include/gdb_nerf_hip.h gdb_dense_map_layout)."""
+        f = self._need_frame()
+        out = (C.c_size_t * 2)()
+        _lib.check(self.lib.gdb_dense_map_layout(C.byref(self.cfg), C.byref(f), out))
+        rows = f.B * f.H
+        t = self._ws[out[0]:out[0] + 4 * rows * out[1]].view(torch.int32).view(rows, out[1]).to(torch.int64)
+        return t & 0xFFFFFFFF
+
     def _need_frame(self) -> GdbFrame:
         if self._frame is None:
             # bundle_sampler.py:220-221 of the reference
             raise ValueError("Rays have not been built yet. Please call prepare() first.")
         return self._frame
+
+    def _sched(self) -> int:
+        """The schedule argument of a render call: this engine's schedule, plus the plan-is-current flag while the depth prior
+        the last prepare() consumed is untouched."""
+        dr = self._keep.get("depth_range")
+        ready = self._plan_key is not None and dr is not None and (dr.data_ptr(), dr._version) == self._plan_key
+        return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0)
 
     @property
     def n_bundles(self) -> int:
@@ -468,7 +490,7 @@ class HotPathEngine:
         bf, depth, opac = out
         _chk(bf, "bundle_feat", (nb, self.Q)); _chk(depth, "depth", (nb,)); _chk(opac, "opacity", (nb,))
         _lib.check(self.lib.gdb_render_bundles_fused(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
-                                                     int(row_begin), int(row_end), int(precision), int(self.schedule), bf.data_ptr(),
+                                                     int(row_begin), int(row_end), int(precision), self._sched(), bf.data_ptr(),
                                                      depth.data_ptr(), opac.data_ptr(), self._stream()))
         return bf, depth, opac
 
@@ -489,6 +511,6 @@ class HotPathEngine:
             out = self._buf("render.packed", (nb, self.Q + 2)) if full else torch.zeros((nb, self.Q + 2), device=self.device)
         _chk(out, "out", (nb, self.Q + 2))
         _lib.check(self.lib.gdb_render_bundles_packed(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
-                                                      int(row_begin), int(row_end), int(precision), int(self.schedule),
+                                                      int(row_begin), int(row_end), int(precision), self._sched(),
                                                       out.data_ptr(), self._stream()))
         return out

@@ -99,9 +99,14 @@ int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7
  * bundle-map row (B*H rows) out[1] int32 values [n_windows, first bundle of window 0 .. n_windows-1, W]; a window is the run of
  * consecutive bundles whose first sample offset inside the row (exclusive prefix of the per-bundle sample counts,
  * bundle_sampler.py:179-189) falls into [out[2] * w, out[2] * (w + 1)) — at most 32 samples.  out[0] = byte offset of the
- * first row record.  Built by gdb_prepare when the frame carries d_depth_range and the config is adaptive with S_max > 3, else by
- * the first render call that asks for GDB_SCHED_DENSE. */
+ * first row record.  Built by gdb_prepare FROM THE CONTENTS OF d_depth_range AT THAT TIME when the frame carries it and the
+ * config is adaptive; a dense render that is not told the plan is current (GDB_SCHED_PLAN_READY) rebuilds it first. */
 int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[3]);
+/* ... and the compacted sample list beside it (bundle_sampler.py:182-189: bundle-major, sample-minor): per bundle-map row out[1]
+ * uint32 entries, entry s = the sample at offset s of the row as [bundle x | slot k << 16 | count of the bundle << 24],
+ * 0xFFFFFFFF past the row's last sample.  out[0] = byte offset of the first row.  Window w of the plan is the wave that reads
+ * entries [L w, L w + 32) and keeps those whose bundle starts inside [L w, L (w + 1)). */
+int gdb_dense_map_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[2]);
 
 /* ---- MLP weights -------------------------------------------------------------------- */
 /* Number of floats in the packed weight buffer for cfg (fp32 section + MFMA-fragment
@@ -207,9 +212,12 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
  *   (bundle_sampler.py:182-189): one wave per <= 32 consecutive samples of a bundle-map row, composite across lanes
- *   (uses the per-row plan gdb_prepare builds from d_depth_range when GDB_SCHED_AUTO will take this schedule — adaptive
- *   counts with S_max > 3; an explicit GDB_SCHED_DENSE on other shapes builds the plan itself, into the plan region of
- *   d_workspace — the one place a render call writes the workspace).
+ *   (GDB_SCHED_AUTO takes it for adaptive counts.  It needs the per-row plan + sample list in d_workspace: by default the render
+ *   call builds them itself from frame->d_depth_range, a small launch of its own on the same stream — the one place a render
+ *   call writes the workspace.  gdb_prepare builds the same plan inside its own launch when the frame it is given carries
+ *   d_depth_range and the config is adaptive; a caller that has NOT changed the contents of d_depth_range since that
+ *   gdb_prepare may OR GDB_SCHED_PLAN_READY into `schedule` to skip the rebuild.  With the flag set on a stale or missing plan
+ *   the result is undefined but memory-safe: the kernel clamps everything it reads from the plan to the frame.)
  * Both are per-call arguments: the library keeps no process-global state (two engines with different settings may
  * interleave calls on different streams or threads).
  * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
@@ -220,6 +228,7 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2
 #define GDB_SCHED_DENSE 3
+#define GDB_SCHED_PLAN_READY 0x100 /* flag: the dense plan in d_workspace was built by gdb_prepare from the current d_depth_range */
 int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
                              const float* d_packed_weights, int32_t row_begin, int32_t row_end,
                              int32_t precision, int32_t schedule, float* d_bundle_feat, float* d_depth,

@@ -46,7 +46,8 @@ def test_workspace_bytes_and_errors(lib):
     n = C.c_size_t()
     assert lib.gdb_workspace_bytes(C.byref(_cfg()), C.byref(_shape()), C.byref(n)) == 0
     pyr = 3 * 20 * 4 * (256 * 320 + 128 * 160 + 64 * 80 + 32 * 40)
-    assert pyr < n.value < pyr + 2 * 256 * 320 * 4 + 64 * 1024
+    # camera block + pyramid + per-bundle counts / offsets (mirror) + dense plan + sample list (4 B per sample offset of a row)
+    assert pyr < n.value < pyr + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + 96 * 1024
     # reference error: network.py:33-34 ValueError('`Bundle size` must be a power of 2.')
     with pytest.raises(ValueError, match="power of 2"):
         _lib.check(lib.gdb_workspace_bytes(C.byref(_cfg(bundle_size=3)), C.byref(_shape()), C.byref(n)))

@@ -503,6 +503,41 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
             a, b = int(firsts[w]), int(firsts[w + 1])
             assert cnt[r, a:b].sum() <= 32 and b - a <= 32
             assert off[a] >= L * w and (a == 0 or off[a - 1] < L * w) and off[b - 1] < L * (w + 1)
+    # the compacted sample list (bundle_sampler.py:182-189: bundle-major, sample-minor), row by row
+    smap = npy(eng.dense_map())
+    for r in range(B * H):
+        tot = int(cnt[r].sum())
+        xs = np.repeat(np.arange(W), cnt[r])
+        ks = np.concatenate([np.arange(c) for c in cnt[r]])
+        want = xs | (ks << 16) | (np.repeat(cnt[r], cnt[r]) << 24)
+        assert np.array_equal(smap[r, :tot], want)
+        assert np.all(smap[r, tot:] == 0xFFFFFFFF)
+
+
+def test_dense_render_follows_a_depth_prior_changed_after_prepare():
+    """gdb_prepare builds the dense plan from the depth prior as it is at that moment.  A render call may only reuse it while
+    the prior is untouched (GDB_SCHED_PLAN_READY, which the engine sets from the tensor's storage and version counter); after an
+    in-place change the dense render must rebuild the plan itself and follow the NEW prior - checked against the oracle."""
+    frame = synthetic.make_frame(64, 80, V=3, seed=23)
+    w = synthetic.make_nerf_weights(seed=2)
+    eng = engine_for(frame, w, (3, 1), max_num_samples=6, is_adaptive=True)
+    a = [t.clone() for t in eng.render()]
+    assert eng._sched() & 0x100                       # prepared plan, prior untouched: reused
+    dr = eng._keep["depth_range"]
+    mid, half = 0.5 * (dr[:, 0] + dr[:, 1]), 0.5 * (dr[:, 1] - dr[:, 0])
+    dr[:, 0].copy_(mid - 2.5 * half); dr[:, 1].copy_(mid + 2.5 * half)   # in place: wider prior, more samples per bundle
+    assert not (eng._sched() & 0x100)                 # version counter moved: the render call rebuilds the plan
+    bf, depth, opac = eng.render()
+    f2 = dict(frame); f2["depth_range"] = npy(dr)
+    obf, od, oo = oracle.hot_path(f2, w, max_num_samples=6, is_adaptive=True)
+    assert max_abs(npy(bf), obf) <= 5e-4 and max_abs(npy(depth) / np.abs(od).max(), od / np.abs(od).max()) <= 2e-3
+    assert max_abs(npy(bf), npy(a[0])) > 1e-3         # and it is a different image
+    # a C caller that sets the flag on a stale plan gets an undefined but memory-safe render (clamped reads): just run it
+    eng.prepare({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in frame.items()})
+    eng._keep["depth_range"][:, 1].add_(40.0)         # the prepared plan no longer matches the prior
+    eng.schedule = 3 | 0x100
+    eng._plan_key = None
+    eng.render(); torch.cuda.synchronize()
 
 
 def test_engines_with_different_settings_interleave():

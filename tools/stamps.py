@@ -9,7 +9,7 @@ os.environ["GDB_NERF_LIB"] = _b.build(tag="diag", extra=["-DGDB_DIAG", "-DGDB_DE
 from gdb_nerf_amd import synthetic, _lib
 from gdb_nerf_amd.engine import HotPathEngine
 frame = synthetic.make_frame(512, 640, V=3, seed=0); w = synthetic.make_nerf_weights(seed=0)
-eng = HotPathEngine(max_num_samples=3, is_adaptive=True); eng.load_weights(w)
+eng = HotPathEngine(max_num_samples=3, is_adaptive="--fixed" not in sys.argv); eng.load_weights(w)
 eng.precision = 0 if "f16" in sys.argv else 2 if "f32x" in sys.argv else 1
 sched = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--schedule=")), 1)
 eng.set_schedule(sched)
@@ -44,3 +44,7 @@ clk = np.median((raw12[:, 9] - raw12[:, 0]) / np.maximum(rt1 - rt0, 1) * 0.1)   
 busy = ((rt1 - rt0).sum() / 100.0) / span_us / 1024        # average waves resident per SIMD
 print(f"launch: first wave start -> last wave end {span_us:.1f} us ({launch_us:.1f} us between events); shader clock while the waves ran "
       f"{clk:.2f} GHz (median, stamped build); {busy:.2f} waves resident per SIMD on average")
+
+# concurrency over the launch: waves resident per SIMD at 16 instants (s_memrealtime, 100 MHz); shows fill, steady state and tail
+ts = np.linspace(rt0.min(), rt1.max(), 18)[1:-1]
+print("resident waves per SIMD over the launch:", " ".join(f"{((rt0 <= t) & (rt1 > t)).sum() / 1024:.2f}" for t in ts))
