@@ -31,10 +31,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
 CONTRACT = {"gdb_ops.hip": "off", "gdb_mlp.hip": "off", "gdb_fused.hip": "fast-honor-pragmas", "gdb_costvol.hip": "off", "gdb_merge.hip": "off", "gdb_decoder.hip": "off"}
 
 
-# Kernels whose private segment may only hold register spills — never data.  The round-1 "packed f32" corruption was a
-# private-memory round trip of a weight struct; the fused kernels must keep every struct in registers.
-# k_render_fused (the c2-class schedule) must not touch scratch at all.
-NO_SCRATCH = ("k_render_fused",)
+# Kernels that must not touch private memory at all (no vector spill, no struct parked in scratch).  The round-1 "packed f32"
+# corruption was a private-memory round trip of a weight struct; every fused kernel keeps its data in registers.
+NO_SCRATCH = ("k_render_",)
 
 
 def parse_resource_usage(text: str) -> dict:
@@ -100,10 +99,15 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra=()) -
         rest = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and "remark:" not in l)
         if verbose and rest.strip():
             print(rest)
+    try:  # the compiler the numbers (and the scratch finding of DESIGN.md §4.1) belong to
+        ver = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout.strip().splitlines()
+        usage["_toolchain"] = {"hipcc": " | ".join(l.strip() for l in ver if l.strip())[:400], "flags": " ".join([*FLAGS, *extra])}
+    except OSError as e:
+        usage["_toolchain"] = {"hipcc": f"unknown ({e})"}
     with open(os.path.join(objdir, "resource_usage.json"), "w") as f:
         json.dump(usage, f, indent=1)
     if "-DGDB_XP_PK=1" not in extra:  # (the in-tree reproducer of the private-memory corruption is the one build allowed to)
-        bad = {k: v for u in usage.values() for k, v in u.items() if any(n in k for n in NO_SCRATCH) and v.get("scratch_bytes_per_lane", 0) > 0}
+        bad = {k: v for src, u in usage.items() if not src.startswith("_") for k, v in u.items() if any(n in k for n in NO_SCRATCH) and v.get("scratch_bytes_per_lane", 0) > 0}
         if bad:
             raise RuntimeError(f"kernels that must keep their data in registers use private memory: {bad}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]

@@ -117,16 +117,20 @@ class Network(nn.Module):
             return eng.render_packed()
         world, rank = dist.get_world_size(), dist.get_rank()
         C = eng.Q + 2
+        # RCCL ("nccl") moves device tensors; a gloo group (CPU tests, the one-GPU rehearsal) exchanges host copies
+        stage = dist.get_backend() == "gloo"
         if B == 1:  # one contiguous strip per rank: in-place all-gather, buffers cached per shape
             g = self._gather
-            if g is None or (g.H, g.W, g.C, g.world, g.rank) != (H, W, C, world, rank) or g.full.device != eng.device:
-                g = self._gather = StripGather(H, W, C, world, rank, eng.device, dist)
+            if g is None or (g.H, g.W, g.C, g.world, g.rank) != (H, W, C, world, rank) or g.full.device != torch.device(eng.device):
+                g = self._gather = StripGather(H, W, C, world, rank, eng.device, dist, stage_cpu=stage)
             r0, r1 = g.strip
             eng.render_packed(r0, r1, None, g.full)
             return g.gather()
         from ...parallel import row_strip
         r0, r1 = row_strip(H, rank, world)
         full = eng.render_packed(r0, r1)  # fresh, zero-filled outside the strip
+        if stage and full.is_cuda:
+            return gather_strips(full.cpu(), H, world, dist, B=B).to(full.device)
         return gather_strips(full, H, world, dist, B=B)
 
     def render_bundles(self, rgbs_feat_rgb_dir, vox_feat, z_vals, indices, samples_per_bundle):

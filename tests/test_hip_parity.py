@@ -334,8 +334,9 @@ def test_fused_degenerate_geometry(kind, mode):
 
 
 def test_fused_matches_unfused_at_full_size(mode):
-    """c2 (BASELINE.json configs[1]) is too big for the oracle in a test; at full size the fused kernel is
-    checked against the fp32 operator chain, itself oracle-checked above, plus size-independent properties."""
+    """c2 (BASELINE.json configs[1]) at full size under every (schedule, precision) mode of the matrix: the fused kernel against the
+    fp32 operator chain (which test_c2_full_size_against_the_oracle below checks against the oracle itself, as it does the fused
+    kernel), plus size-independent properties."""
     frame = synthetic.make_frame(512, 640, V=3, seed=0)
     w = synthetic.make_nerf_weights(seed=0)
     eng = engine_for(frame, w, mode, max_num_samples=3, is_adaptive=True)
@@ -378,6 +379,59 @@ def test_c2_full_size_against_the_oracle():
                   f"PSNR delta {dpsnr:.2e} dB")
             assert e <= tol and dpsnr <= 0.05
             assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max()) and max_abs(npy(opac), oo) <= 1e-5
+
+
+@pytest.mark.parametrize("name,Ho,Wo,S,scene,seed", [("c3 640x960", 640, 960, 3, "llff", 0), ("c4 800x800", 800, 800, 6, "nerf", 0)])
+def test_c3_c4_full_size_against_the_oracle(name, Ho, Wo, S, scene, seed):
+    """BASELINE.json configs[2] (as configs/llff_eval.yaml resizes it: 640x960) and configs[3] (800x800, S_max 6 adaptive) at
+    their full sizes, directly against the CPU oracle: the fp32 operator chain, and the fused kernel at fp32 under the schedule
+    GDB_SCHED_AUTO takes (dense) - same bounds as c2.  Reference: bundle_sampler.py:355-359 (the mip fetch whose chain length
+    differs per map size), configs/llff_eval.yaml:18,23."""
+    frame = synthetic.make_frame(Ho, Wo, V=3, scene=scene, seed=seed)
+    w = synthetic.make_nerf_weights(seed=0)
+    with np.errstate(all="ignore"):
+        obf, od, oo, aux = oracle.hot_path(frame, w, max_num_samples=S, is_adaptive=True, return_intermediates=True)
+    eng = engine_for(frame, w, max_num_samples=S, is_adaptive=True)
+    smp = eng.sample()
+    assert np.array_equal(npy(smp["samples_per_bundle"]), aux["samples"]["samples_per_bundle"].astype(np.int32))
+    ubf, ud, uo = eng.render_unfused()
+    eu = max_abs(npy(ubf), obf)
+    bf, depth, opac = eng.render(precision=1)   # GDB_SCHED_AUTO
+    e = max_abs(npy(bf), obf)
+    dpsnr = _psnr_delta(npy(bf), obf, Ho // 2, Wo // 2)
+    print(f"{name} vs oracle: fp32 operator chain max abs err {eu:.3e}; fused fp32 (auto schedule) {e:.3e}, PSNR delta {dpsnr:.2e} dB")
+    assert eu <= 2e-4 and max_abs(npy(ud), od) <= 1e-4 * float(np.abs(od).max()) and max_abs(npy(uo), oo) <= 1e-5
+    assert e <= FUSED_TOL_F32 and dpsnr <= 0.05
+    assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max()) and max_abs(npy(opac), oo) <= 1e-5
+
+
+def test_hot_path_section_allocates_nothing_per_frame():
+    """With `reuse_outputs` (what Network.forward sets) the per-frame section - prepare, packed render, decoder, merge - runs out
+    of per-engine buffers: the caching allocator sees no allocation across 100 frames, and the results equal fresh-tensor calls."""
+    frame = synthetic.make_frame(128, 160, V=3, seed=9)
+    eng = engine_for(frame, synthetic.make_nerf_weights(seed=9), max_num_samples=3, is_adaptive=True)
+    from gdb_nerf_amd.networks.gdb_nerf.decoder_rdn import Decoder
+    torch.manual_seed(0)
+    dec = Decoder(27, 3, num_feats=64, num_layers=3, upscale_factor=2)
+    eng.load_decoder_weights(dec.state_dict(), 3)
+    dev = dev_frame(frame)
+
+    def step():
+        eng.prepare(dev)
+        packed = eng.render_packed()
+        return eng.merge_packed(packed, eng.decode(packed), True)
+    fresh = [t.clone() for t in step()]
+    eng.reuse_outputs = True
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize()
+    n0 = torch.cuda.memory_stats()["allocation.all.allocated"]
+    for _ in range(100):
+        out = step()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] == n0
+    for a, b in zip(fresh, out):
+        assert torch.equal(a, b)
 
 
 def test_fused_is_deterministic_at_full_size(mode):

@@ -54,6 +54,46 @@ def test_network_has_reference_checkpoint_layout(f7):
         make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "3"]))
 
 
+def test_decoder_gating_and_packed_weight_invalidation(monkeypatch):
+    """The HIP decoder is built for bundle_size 2 and 1..3 dense blocks: any other decoder keeps the PyTorch module (as before it
+    existed).  Its packed weights are re-packed whenever a parameter's storage or version changes - `p.data = ...`,
+    load_state_dict(assign=True) and load_state_dict itself included; an in-place write through `.data` (which PyTorch does not
+    version) needs invalidate_packed_weights()."""
+    from gdb_nerf_amd.networks.gdb_nerf import network as netmod
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "4"])).hip_decoder is False
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "3"])).hip_decoder is True
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.hip_decoder", "False"])).hip_decoder is False
+
+    class FakeEngine:
+        def __init__(self, **kw):
+            self.device, self.weights, self.dec_loads, self.nerf_loads = torch.device(kw["device"]), None, 0, 0
+        def load_weights(self, sd):
+            self.weights, self.nerf_loads = True, self.nerf_loads + 1
+        def load_decoder_weights(self, sd, n):
+            self.dec_loads += 1
+    monkeypatch.setattr(netmod, "HotPathEngine", FakeEngine)
+    net = make_network(make_cfg("configs/dtu_eval.yaml")).eval()
+    eng = net._get_engine("cpu")
+    assert (eng.dec_loads, eng.nerf_loads) == (1, 1)
+    net._get_engine("cpu")
+    assert (eng.dec_loads, eng.nerf_loads) == (1, 1)                    # unchanged parameters: no re-pack
+    p = net.upsampler.in_conv.weight
+    p.data = p.data.clone()                                             # new storage, same version counter
+    assert net._get_engine("cpu").dec_loads == 2
+    with torch.no_grad():
+        p.add_(1.0)                                                     # versioned in-place write
+    assert net._get_engine("cpu").dec_loads == 3
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)                                # new tensors, version counters reset
+    assert (net._get_engine("cpu").dec_loads, eng.nerf_loads) == (4, 2)
+    net.load_state_dict(sd)                                             # copy_ into the same storage: the load hook invalidates
+    assert net._get_engine("cpu").dec_loads == 5
+    net.upsampler.in_conv.weight.data.copy_(sd["upsampler.in_conv.weight"])   # unversioned: explicit invalidation
+    assert net._get_engine("cpu").dec_loads == 5
+    net.invalidate_packed_weights()
+    assert net._get_engine("cpu").dec_loads == 6
+
+
 def test_cnns_match_reference_on_cpu(f7):
     """Upstream / downstream CNNs (PyTorch, out of the hot path) reproduce the reference's outputs."""
     net = _net(f7)
@@ -113,6 +153,71 @@ def test_network_forward_matches_reference(f7, hot_path, precision, tol):
     gt = np.clip(np.transpose(f7["rgb"][0], (1, 2, 0)) + np.random.default_rng(1).normal(0, 0.03, (64, 96, 3)), 0, 1)
     d_psnr = abs(oracle.psnr(gt, np.transpose(ret["rgb"][0].cpu().numpy(), (1, 2, 0))) - oracle.psnr(gt, np.transpose(f7["rgb"][0], (1, 2, 0))))
     assert d_psnr <= 0.05  # north_star: PSNR within 0.05 dB of the reference path
+
+
+@pytest.mark.gpu
+def test_sharded_forward_at_world_1_is_bit_identical(f7):
+    """`nerf.shard: rows` with a one-rank process group takes the sharded branch (render the strip into the gather buffer, gather,
+    replicated decoder + merge) and must reproduce the unsharded forward bit for bit; two forwards reuse the same buffers."""
+    import torch.distributed as dist
+    from test_parallel import _free_port
+    import os
+    ref = _net(f7).cuda()
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in ref(_batch(f7, "cuda"))[0].items()}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        net = _net(f7, **{"nerf.shard": "rows"}).cuda()
+        with torch.no_grad():
+            for _ in range(2):
+                got = net(_batch(f7, "cuda"))[0]
+        assert net._gather is not None and net._gather.world == 1
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    finally:
+        dist.destroy_process_group()
+
+
+def _rehearsal_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = load_golden("F7_network")
+        net = _net(fx, **{"nerf.shard": "rows"}).cuda()
+        with torch.no_grad():
+            out = net(_batch(fx, "cuda"))[0]
+        q.put((rank, {k: v.cpu().numpy() for k, v in out.items()}, tuple(net._gather.strip)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_forward_two_ranks_on_one_gpu_reproduce_the_single_rank_image(f7):
+    """Rehearsal of the N > 1 product path on the one-GPU box: two fresh child processes share the card, a gloo group stands in for
+    RCCL (the exchange staged through host memory), each rank renders its strip of bundle-map rows inside Network.forward, and
+    both must end with the single-rank image bit for bit (run.py:54-66 calls network(batch) once per frame on every rank)."""
+    import torch.multiprocessing as mp
+    from test_parallel import _free_port
+    ref = _net(f7).cuda()
+    with torch.no_grad():
+        want = {k: v.cpu().numpy() for k, v in ref(_batch(f7, "cuda"))[0].items()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rehearsal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2][1] == res[1][2][0] and res[0][2][0] == 0          # two strips that tile the rows
+    for rank, out, _ in res:
+        for k in want:
+            assert np.array_equal(out[k], want[k]), (rank, k)
 
 
 @pytest.mark.gpu

@@ -245,3 +245,19 @@ def test_volrend_restatements_match_a_padded_cumprod_witness():
     acc = torch.zeros((300, 6)).index_add_(0, ind, torch.from_numpy(np.concatenate((vals, np.ones((n, 1), np.float32)), 1) * got_w[:, None]))
     assert max_abs(feat, acc[:, :4].numpy()) <= 2e-6 and max_abs(depth, acc[:, 4].numpy()) <= 2e-6 and max_abs(opac, acc[:, 5].numpy()) <= 2e-6
     assert np.all(opac[counts == 0] == 0) and np.all(feat[counts == 0] == 0)
+
+
+@pytest.mark.parametrize("Ho,Wo,V,S,adaptive,inv,B,scene", [(64, 80, 3, 3, True, False, 1, "dtu"), (48, 64, 2, 6, True, True, 2, "nerf"),
+                                                             (32, 48, 5, 4, False, False, 1, "dtu")])
+def test_torch_restatement_matches_the_numpy_oracle(Ho, Wo, V, S, adaptive, inv, B, scene):
+    """oracle/gdb_oracle_torch.py (the CPU baseline bench.py times: torch CPU kernels, threaded) against the numpy oracle, which
+    the golden fixtures above pin to the reference: same frames, whole hot path."""
+    import gdb_oracle_torch
+    from gdb_nerf_amd import synthetic
+    fr = synthetic.make_frame(Ho, Wo, V=V, B=B, scene=scene, seed=5)
+    w = synthetic.make_nerf_weights(seed=5)
+    a = oracle.hot_path(fr, w, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    b = gdb_oracle_torch.hot_path(fr, w, max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
+    assert max_abs(a[0], b[0].numpy()) <= 2e-5
+    assert max_abs(a[1] / np.abs(a[1]).max(), b[1].numpy() / np.abs(a[1]).max()) <= 2e-6
+    assert max_abs(a[2], b[2].numpy()) <= 2e-6

@@ -107,3 +107,60 @@ def test_packed_strip_gather_gloo(world, H, W, C):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+class _FakeHotPath:
+    """Stands in for HotPathEngine inside Network._render_packed on the CPU: writes the rows it is asked for, and only those."""
+
+    def __init__(self, truth, B, H):
+        self.truth, self.B, self.H, self.Q, self.device = truth, B, H, truth.shape[1] - 2, torch.device("cpu")
+        self.calls = []
+
+    def render_packed(self, r0=0, r1=None, precision=None, out=None):
+        r1 = self.H if r1 is None else r1
+        self.calls.append((r0, r1))
+        if out is None:
+            out = torch.zeros_like(self.truth)
+        v, t = out.view(self.B, self.H, -1), self.truth.view(self.B, self.H, -1)
+        v[:, r0:r1] = t[:, r0:r1]
+        return out
+
+
+def _network_worker(rank, world, port, B, H, W, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdb_nerf_amd.configs import make_cfg
+        from gdb_nerf_amd.networks import make_network
+        net = make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.shard", "rows"])).eval()
+        ok = net.shard == "rows"
+        for rep in range(2):   # the gather buffers are cached per shape and reused frame after frame
+            truth = torch.arange(B * H * W * 41, dtype=torch.float32).view(B * H * W, 41) + 1000.0 * rep
+            eng = _FakeHotPath(truth, B, H)
+            packed = net._render_packed(eng, B, H, W)
+            ok = ok and bool(torch.equal(packed, truth)) and eng.calls == [row_strip(H, rank, world)]
+        plain = make_network(make_cfg("configs/dtu_eval.yaml")).eval()   # nerf.shard defaults to none: whole frames on every rank
+        eng = _FakeHotPath(truth, B, H)
+        ok = ok and bool(torch.equal(plain._render_packed(eng, B, H, W), truth)) and eng.calls == [(0, H)]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,H,W", [(2, 1, 8, 5), (2, 1, 7, 4), (2, 2, 5, 3)])
+def test_network_forward_shards_rows_over_ranks(world, B, H, W):
+    """`nerf.shard: rows` (north_star: rays shard across the GPUs of a node): with torch.distributed initialised,
+    Network.forward's hot-path section renders this rank's strip of bundle-map rows and ONE all-gather leaves the whole packed
+    bundle map on every rank (even and uneven H, batch > 1); without the key every rank renders whole frames.
+    Reference call site: network.py:145-169, driven once per frame by run.py:54-66."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_network_worker, args=(r, world, port, B, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]

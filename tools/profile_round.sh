@@ -32,8 +32,16 @@ for p in ("f32", "f32x", "f16"):
     res["pmc_per_dispatch"][p] = vals
     for k in vals:
         if "k_render" in k and "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]:
-            name = "k_render_solo" if "solo" in k else "k_render_fused"
+            name = "k_render_solo" if "solo" in k else "k_render_dense" if "dense" in k else "k_render_fused"
             res["traffic_bytes"][f"{wl}:{name}:{p}"] = (2.0 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0   # KB -> bytes, read side doubled (gfx950)
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print("fused kernel HBM traffic per launch (bytes):", res["traffic_bytes"])
+# traffic.json for bench.py's roofline.traffic, stamped with the kernel source it was measured on (bench.py refuses it otherwise)
+import hashlib
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+sha = hashlib.sha256(open(os.path.join("$ROOT", "gdb-nerf_amd", "csrc", "gdb_fused.hip"), "rb").read()).hexdigest()[:16]
+tj = dict(res["traffic_bytes"])
+tj["_kernel_source_sha256_16"] = sha
+tj["_source"] = "profiles/$TAG/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, per launch: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; MI355X guide, HBM section)"
+json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 PY
