@@ -326,9 +326,53 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // dir2|dir3) - the same rounding, just earlier - which makes a view 33 rows: three views are 12,672 B, under the 12,800 B
 // at which twelve one-wave workgroups fit a CU (the LDS allocation granule is 1280 B: tools/ubench/simd_map.hip).
 // (The f32 path stages the 4 direction values as fp32 rows: 35 rows.)
-constexpr int ROW_FEAT = 12, ROW_DIR = NBLEND;
-template <int PREC> constexpr int stage_v() { return (NBLEND + (PREC != GDB_PREC_F16 ? 4 : 2)) * 32; }  // floats per (wave, view): 4224 / 4480 B
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
+// GDB_PREC_F16 goes one step further: the 12 sub-ray colours (values in [0, 1]) are staged as 6 rows of packed halves too (round
+// to nearest: 2.4e-4 at most, inside that path's 2e-3 bound), 27 rows = 3,456 B per view, so that five views (c5) are 17,280 B per
+// wave and a CU holds 9 waves instead of 7.
+// Rows of a staged view: [colours | feat (+) rgb 19 | dir]
+template <int PREC> constexpr int row_feat() { return PREC == GDB_PREC_F16 ? 6 : 12; }
+template <int PREC> constexpr int row_dir() { return row_feat<PREC>() + GDB_CFR; }
+template <int PREC> constexpr int stage_v() { return (row_dir<PREC>() + (PREC != GDB_PREC_F16 ? 4 : 2)) * 32; }  // floats per (wave, view): 3456 / 4480 B
+// Blended output channels of lane (j, h), register i of 16: the 6 colours of ITS OWN two sub-rays (channel c b^2 + 2h + e, the
+// ones its half gathered), then 10 (half 0) / 9 (half 1) channels of feat (+) rgb.  -1: no channel (half 1's last register).
+__device__ __forceinline__ constexpr int own_chan(int h, int i) {
+    return i < 6 ? (i >> 1) * 4 + 2 * h + (i & 1) : (10 * h + i - 6 < GDB_CFR ? 12 + 10 * h + i - 6 : -1);
+}
+// Store the lane's 16 blended values (val(i)) into a channel-major record rec[channel * COMP_LD + col]: the half only moves two
+// base addresses, every row offset is a compile-time constant.
+template <class F>
+__device__ __forceinline__ void store_own16(float* rec, int col, int h, F val) {
+    float* ra = rec + h * (2 * COMP_LD) + col;    // colours: channel c b^2 + 2h + e
+    float* rb = rec + h * (10 * COMP_LD) + col;   // feat (+) rgb: channel 12 + 10h + (i - 6)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ra[((i >> 1) * 4 + (i & 1)) * COMP_LD] = val(i);
+#pragma unroll
+    for (int i = 6; i < 15; ++i) rb[(12 + i - 6) * COMP_LD] = val(i);
+    if (h == 0) rb[(12 + 9) * COMP_LD] = val(15);  // half 1's register 15 carries no channel
+}
+// This lane's 16 staged values of one view in that order (what the softmax blend of nerf.py:110 accumulates)
+template <int PREC>
+__device__ __forceinline__ void load_blend16(const float* __restrict__ st, int j, int h, float val[16]) {
+    if constexpr (PREC == GDB_PREC_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned* su = (const unsigned*)st + h * 32;   // packed colour rows: row 2c + h = (sub-ray 2h, sub-ray 2h + 1) of colour c
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const h2 p = __builtin_bit_cast(h2, su[(2 * c) * 32 + j]);
+            val[2 * c] = (float)p.x; val[2 * c + 1] = (float)p.y;
+        }
+    } else {
+        const float* sa = st + h * (2 * 32);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) val[i] = sa[((i >> 1) * 4 + (i & 1)) * 32 + j];
+    }
+    const float* sb = st + h * (10 * 32);
+#pragma unroll
+    for (int i = 6; i < 15; ++i) val[i] = sb[(row_feat<PREC>() + i - 6) * 32 + j];
+    const float last = sb[(row_feat<PREC>() + 9) * 32 + j];   // half 0: channel 9 of feat (+) rgb; half 1: past the 19 channels (a dir row)
+    val[15] = h ? 0.f : last;
+}
 constexpr int COMP_CH = NOUT + 1;            // 39 channels + z
 constexpr int COMP_ALPHA = (COMP_CH * COMP_LD + 3) / 4 * 4;  // alpha [32] of the slot
 constexpr int COMP_WN = COMP_ALPHA + 32;                     // normalised weight [32]
@@ -581,13 +625,14 @@ extern __shared__ float4 smem4[];
 template <bool X> struct Tail { float fv[12]; Frag<X> T0, T1; };
 template <bool X>
 __device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j, int h) {
+    constexpr int RF = row_feat<X ? GDB_PREC_F32X : GDB_PREC_F16>(), RD = row_dir<X ? GDB_PREC_F32X : GDB_PREC_F16>();
     Tail<X> t;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int ch = 8 * s + 4 * h + e;
-            t.fv[4 * s + e] = ch < GDB_CFR ? st[(ROW_FEAT + ch) * 32 + j] : 0.f;
+            t.fv[4 * s + e] = ch < GDB_CFR ? st[(RF + ch) * 32 + j] : 0.f;
         }
     if constexpr (X) {  // the direction code is staged as four fp32 rows (as for GDB_PREC_F32)
         float v1[8];
@@ -595,12 +640,12 @@ __device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j
         for (int i = 0; i < 3; ++i) v1[i] = t.fv[8 + i];  // channels 16..18 (half 0) / zeros (half 1)
         v1[3] = h == 0 ? 1.f : 0.f;                        // tv[19] is padding: constant one that carries view_fc's bias
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v1[4 + i] = h == 0 ? st[(ROW_DIR + i) * 32 + j] : 0.f;  // dir sits at tv[24..27], owned by half 0
+        for (int i = 0; i < 4; ++i) v1[4 + i] = h == 0 ? st[(RD + i) * 32 + j] : 0.f;  // dir sits at tv[24..27], owned by half 0
         t.T0 = split8(t.fv);
         t.T1 = split8(v1);
     } else {
         const unsigned* su = (const unsigned*)st;
-        const unsigned d01 = h == 0 ? su[(ROW_DIR + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(ROW_DIR + 1) * 32 + j] : 0u;
+        const unsigned d01 = h == 0 ? su[(RD + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(RD + 1) * 32 + j] : 0u;
         const half2v p01 = __builtin_bit_cast(half2v, d01), p23 = __builtin_bit_cast(half2v, d23);
 #pragma unroll
         for (int i = 0; i < 8; ++i) t.T0.hi[i] = (_Float16)t.fv[i];
@@ -794,26 +839,37 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rgb[e][c] = u;
         }
+        constexpr int RF = row_feat<PREC>(), RD = row_dir<PREC>();
+        if constexpr (PREC == GDB_PREC_F16) {  // colours as packed halves: row 2c + h = (sub-ray 2h, 2h + 1) of colour c
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            unsigned* su = (unsigned*)st;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+            for (int c = 0; c < 3; ++c) {
+                const h2 p = {(_Float16)rgb[0][c], (_Float16)rgb[1][c]};
+                su[(2 * c + h) * 32 + j] = __builtin_bit_cast(unsigned, p);
+            }
+        } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) st[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
+        }
         const float* ff = (const float*)feat;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
-        st[(ROW_FEAT + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
-        if (h == 0) st[(ROW_FEAT + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
+            for (int e = 0; e < 4; ++e) st[(RF + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
+        st[(RF + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
+        if (h == 0) st[(RF + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
         if (PREC != GDB_PREC_F16) {  // four fp32 rows; both halves computed the same code, each stores two of them
-            st[(ROW_DIR + 2 * h) * 32 + j] = h ? dir[2] : dir[0];
-            st[(ROW_DIR + 2 * h + 1) * 32 + j] = h ? dir[3] : dir[1];
+            st[(RD + 2 * h) * 32 + j] = h ? dir[2] : dir[0];
+            st[(RD + 2 * h + 1) * 32 + j] = h ? dir[3] : dir[1];
         } else if (h == 0) {
             typedef _Float16 half2v __attribute__((ext_vector_type(2)));
             const half2v p01 = {(_Float16)dir[0], (_Float16)dir[1]}, p23 = {(_Float16)dir[2], (_Float16)dir[3]};
             unsigned* su = (unsigned*)st;
-            su[(ROW_DIR + 0) * 32 + j] = __builtin_bit_cast(unsigned, p01);
-            su[(ROW_DIR + 1) * 32 + j] = __builtin_bit_cast(unsigned, p23);
+            su[(RD + 0) * 32 + j] = __builtin_bit_cast(unsigned, p01);
+            su[(RD + 1) * 32 + j] = __builtin_bit_cast(unsigned, p23);
         }
     }
 }
@@ -843,7 +899,7 @@ __device__ __forceinline__ bool slot_gather(const DevFrame& f, float* stage, flo
 // phase's fragments (they fly under this phase's MFMAs and VALU work), then computes with fragments loaded one phase
 // earlier.  The fences keep the compiler from moving the loads any further (hoisting all ~45 of them spills), so
 // without this each phase's first MFMA waits a full L2 round trip.
-// Outputs per lane (j, h): bacc[i] = blended channel 16h+i of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
+// Outputs per lane (j, h): bacc[i] = blended channel own_chan(h, i) of [rgbs | feat | rgb] (31 used), fhv[i] = ReLU'd feat_head
 // channel 4h+i, sig = sigma pre-activation (valid in half 0).
 template <bool X>
 __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __restrict__ mf, const float* stage, const float vox[4], int lane, int j,
@@ -1016,12 +1072,10 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
             float mn = fmaxf(mx, uv);
             float sc_old = __expf(mx - mn), e = __expf(uv - mn);
             den = den * sc_old + e;
+            float val[16];
+            load_blend16<X ? GDB_PREC_F32X : GDB_PREC_F16>(st, j, h, val);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int c = 16 * h + i;
-                float val = c < NBLEND ? st[c * 32 + j] : 0.f;
-                bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
-            }
+            for (int i = 0; i < 16; ++i) bacc[i] = bacc[i] * sc_old + e * val[i];  // nerf.py:110
             mx = mn;
         }
         float r = frcp(den);
@@ -1112,17 +1166,18 @@ __device__ __forceinline__ void finish16(const f32x4& d0, const f32x4& d1, float
 struct Tail32 { float fv[12]; float d[2]; };
 template <bool WITH_D>
 __device__ __forceinline__ Tail32 load_tail32(const float* __restrict__ st, int j, int h) {
+    constexpr int RF = row_feat<GDB_PREC_F32>(), RD = row_dir<GDB_PREC_F32>();
     Tail32 t;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t.fv[4 * s + e] = st[(ROW_FEAT + 8 * s + 4 * h + e) * 32 + j];
-    const float* st2 = st + h * ((ROW_DIR - (ROW_FEAT + 16)) * 32);  // half 0: channels 16, 17, 18, (dir 0); half 1: dir 0..3
+        for (int e = 0; e < 4; ++e) t.fv[4 * s + e] = st[(RF + 8 * s + 4 * h + e) * 32 + j];
+    const float* st2 = st + h * ((RD - (RF + 16)) * 32);  // half 0: channels 16, 17, 18, (dir 0); half 1: dir 0..3
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t.fv[8 + e] = st2[(ROW_FEAT + 16 + e) * 32 + j];
+    for (int e = 0; e < 4; ++e) t.fv[8 + e] = st2[(RF + 16 + e) * 32 + j];
     if (WITH_D) {
-        t.d[0] = st[(ROW_DIR + h) * 32 + j];
-        t.d[1] = st[(ROW_DIR + 2 + h) * 32 + j];
+        t.d[0] = st[(RD + h) * 32 + j];
+        t.d[1] = st[(RD + 2 + h) * 32 + j];
     } else t.d[0] = t.d[1] = 0.f;
     return t;
 }
@@ -1289,12 +1344,10 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
             float mn = fmaxf(mx, uv);
             float sc_old = __expf(mx - mn), e = __expf(uv - mn);
             den = den * sc_old + e;
+            float val[16];
+            load_blend16<GDB_PREC_F32>(st, j, h, val);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int c = 16 * h + i;
-                float val = c < NBLEND ? st[c * 32 + j] : 0.f;
-                bacc[i] = bacc[i] * sc_old + e * val;  // nerf.py:110
-            }
+            for (int i = 0; i < 16; ++i) bacc[i] = bacc[i] * sc_old + e * val[i];  // nerf.py:110
             mx = mn;
         }
         float r = frcp(den);
@@ -1318,11 +1371,7 @@ __device__ __forceinline__ void slot_mlp(const DevFrame& f, const float* __restr
     if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mf, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
     // hand this slot to the composite (the record may alias this wave's staging area, dead by now)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int c = 16 * h + i;
-        if (c < NBLEND) ck[c * COMP_LD + j] = act ? bacc[i] : 0.f;
-    }
+    store_own16(ck, j, h, [&](int i) { return act ? bacc[i] : 0.f; });
 #pragma unroll
     for (int i = 0; i < 4; ++i) ck[(NBLEND + 4 * h + i) * COMP_LD + j] = act ? fhv[i] : 0.f;
     if (h == 0) {
@@ -1500,7 +1549,7 @@ __global__ void __launch_bounds__(64 * WAVES, (LOOP || WAVES > 4) ? 2 : 3) k_ren
 // One wave = one 32-bundle row segment and ALL its sample slots, one after the other; the composite runs in registers.
 // Against the workgroup-composite kernel above this drops the per-slot LDS record, the barrier wait for the slowest
 // slot and the composite pass, and a frame's waves fit on the chip in fewer rounds (c2: 2560 waves, one round).
-// Lane (j, h) owns blended channels 16h..16h+15 and feat_head channels 4h..4h+3 of bundle j; transmittance, weight
+// Lane (j, h) owns blended channels own_chan(h, 0..15) and feat_head channels 4h..4h+3 of bundle j; transmittance, weight
 // sum and depth are kept by both halves.  utils.py:35-41 (weights), :109-119 (sums), network.py:83-89 (depth).
 // WPS = waves per SIMD the register allocation is held to: 3 where LDS admits 12 waves per CU (V <= 3 at f16), else 2.
 template <int PREC, int WPS>
@@ -1578,11 +1627,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     const float rden = 1.f / fmaxf(wsum, 1e-6f);
     __builtin_amdgcn_wave_barrier();
     float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int c = 16 * h + i;
-        if (c < NBLEND) o[c * COMP_LD + j] = oacc[i] * rden;
-    }
+    store_own16(o, j, h, [&](int i) { return oacc[i] * rden; });
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + j] = of[i] * rden;
     if (h == 0) {
@@ -1742,7 +1787,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
-    float v[22];  // 0..15 blended channels 16h.., 16..19 feat_head 4h.., 20 weight, 21 weight x depth
+    float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
     float sig;
     {
         float bacc[16], fhv[4];
@@ -1809,11 +1854,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity; column = bundle of the window
     if (act && k == 0) {
         const float rden = 1.f / fmaxf(v[20], 1e-6f);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int c = 16 * h + i;
-            if (c < NBLEND) o[c * COMP_LD + bj] = v[i] * rden;
-        }
+        store_own16(o, bj, h, [&](int i) { return v[i] * rden; });
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + bj] = v[16 + i] * rden;
         if (h == 0) {
@@ -1899,6 +1940,9 @@ static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t
     return hipGetLastError();
 }
 
+// one-wave workgroups a CU holds by LDS (allocated in 1280-byte granules out of 160 KiB)
+static size_t waves_by_lds(size_t lds) { return (size_t)(160 * 1024) / ((lds + 1279) / 1280 * 1280); }
+
 template <int PREC>
 static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const void* ws, int sched, bool plan_ready, hipStream_t st) {
     const int S = cfg->max_num_samples, V = fr->V;
@@ -1937,15 +1981,16 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
         a.alias = 0;
         a.ntiles = a.nrows * a.f.planMW;  // per batch item, worst case (every bundle at S_max)
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+        // the 3-waves-per-SIMD build (168 registers) wherever LDS admits more than the 8 waves per CU of the 2-wave build
         bool three = false;
-        if constexpr (PREC != GDB_PREC_F32) three = 12 * (solo_lds + pad) <= lds_max;
+        if constexpr (PREC != GDB_PREC_F32) three = waves_by_lds(solo_lds + pad) > 8 || 2 * waves_by_lds(2 * (solo_lds + pad)) > 8;
         if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, (solo_lds + pad + 15) / 16 * 16, st); }
         if (!three) e = launch_dense<PREC, 2>(a, (solo_lds + pad + 15) / 16 * 16, st);
     } else if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
         a.alias = 0;
         // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
         bool three = false;
-        if constexpr (PREC == GDB_PREC_F16) three = 12 * (solo_lds + pad) <= lds_max;
+        if constexpr (PREC == GDB_PREC_F16) three = waves_by_lds(solo_lds + pad) > 8;
         if constexpr (PREC == GDB_PREC_F16) { if (three) e = launch_solo<GDB_PREC_F16, 3>(a, grid, solo_lds + pad, st); }
         if (!three) e = launch_solo<PREC, 2>(a, grid, solo_lds + pad, st);
     } else if (rec_fits && S <= 8 && (size_t)S * per_wave <= lds_max) {  // one wave per slot

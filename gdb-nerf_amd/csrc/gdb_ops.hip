@@ -272,18 +272,23 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
 
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
-    if ((int)blockIdx.x > a.ntiles) {  // dense-schedule plan: 4 rows per workgroup
-        const int rowid = ((int)blockIdx.x - a.ntiles - 1) * 4 + (int)(threadIdx.x >> 6);
-        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
-        return;
-    }
-    if ((int)blockIdx.x >= a.ntiles) {
+    // Grid: [camera block | plan workgroups (4 bundle-map rows each) | pyramid tiles].  The serial pieces come FIRST: the camera
+    // block is one short chain of fp64 inverses, a plan row one wave walking a latency chain (strided loads, IEEE divisions, a scan,
+    // scattered stores); dispatched last they ran on after the tiles had drained (k_prepare 10.7 -> 13.7 us when every adaptive
+    // frame got a plan), dispatched first they hide under the tiles.
+    if (blockIdx.x == 0) {
         for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
             if (t % (a.V + 1) == 0 || a.src_exts)
                 cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
         return;
     }
-    const int tx = blockIdx.x % a.tilesX, ty = (blockIdx.x / a.tilesX) % a.tilesY, bv = blockIdx.x / (a.tilesX * a.tilesY);
+    if ((int)blockIdx.x <= a.nplan) {
+        const int rowid = ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);
+        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
+        return;
+    }
+    const int blk = (int)blockIdx.x - 1 - a.nplan;
+    const int tx = blk % a.tilesX, ty = (blk / a.tilesX) % a.tilesY, bv = blk / (a.tilesX * a.tilesY);
     const int x0 = tx * PT_W, y0 = ty * PT_H;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
