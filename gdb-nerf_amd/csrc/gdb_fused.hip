@@ -1779,8 +1779,8 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     int cnt;
     {
         Bundle<4> q;
-        load_bundle<4, true>(f, tc, bi, row, first + bj, q);
-        cnt = q.count;  // (equals the list's count when the plan belongs to this depth prior)
+        load_bundle<4, true, false>(f, tc, bi, row, first + bj, q);
+        q.count = cnt = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
         slot_gather_q<PREC>(f, stage, tc, q, min(k, cnt - 1), bi, j, h, a.skip, act, z, vox);
     }
@@ -1909,26 +1909,31 @@ static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hip
     return hipGetLastError();
 }
 
-// lds: bytes per wave (a multiple of 16); two waves per workgroup where that puts more waves on a CU (1280-byte LDS granules)
+// lds: bytes per wave (a multiple of 16).  NWG waves per workgroup: whichever of 1, 2, 4 puts the most waves on a CU (LDS comes in
+// 1280-byte granules, so several waves' areas in one allocation can fit where single ones lose a wave to the rounding); on a tie
+// the smaller workgroup, unless GDB_DENSE_PREFER_WIDE asks for the larger one (fewer workgroups for the dispatcher to launch).
+#ifndef GDB_DENSE_PREFER_WIDE
+#define GDB_DENSE_PREFER_WIDE 0
+#endif
+template <int PREC, int WPS, int NWG>
+static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG>, done);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(((a.ntiles + NWG - 1) / NWG + 7) / 8 * 8);  // a.ntiles: worst case per batch item; grid y = batch item
+    hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG>), dim3(grid, (unsigned)a.f.B), dim3(64 * NWG), NWG * lds, st, a);
+    return hipGetLastError();
+}
 template <int PREC, int WPS>
 static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
     const size_t gran = 1280, cap = 160 * 1024;
-    const size_t one = cap / ((lds + gran - 1) / gran * gran), two = 2 * (cap / ((2 * lds + gran - 1) / gran * gran));
+    auto waves = [&](size_t n) { return n * lds > cap ? (size_t)0 : n * (cap / ((n * lds + gran - 1) / gran * gran)); };
+    const size_t w1 = waves(1), w2 = waves(2), w4 = waves(4);
     a.wave_floats = (int)(lds / sizeof(float));
-    if (two > one) {
-        static std::atomic<unsigned long long> done2{0};
-        hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 2>, done2);
-        if (e != hipSuccess) return e;
-        const unsigned grid = (unsigned)(((a.ntiles + 1) / 2 + 7) / 8 * 8);  // a.ntiles: worst case per batch item; grid y = batch item
-        hipLaunchKernelGGL((k_render_dense<PREC, WPS, 2>), dim3(grid, (unsigned)a.f.B), dim3(128), 2 * lds, st, a);
-        return hipGetLastError();
-    }
-    static std::atomic<unsigned long long> done{0};
-    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, 1>, done);
-    if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((k_render_dense<PREC, WPS, 1>), dim3(grid, (unsigned)a.f.B), dim3(64), lds, st, a);
-    return hipGetLastError();
+    const bool wide = GDB_DENSE_PREFER_WIDE != 0;
+    if (w4 > w2 && w4 > w1 || (wide && w4 >= w2 && w4 >= w1 && w4 > 0)) return launch_dense_n<PREC, WPS, 4>(a, lds, st);
+    if (w2 > w1 || (wide && w2 >= w1 && w2 > 0)) return launch_dense_n<PREC, WPS, 2>(a, lds, st);
+    return launch_dense_n<PREC, WPS, 1>(a, lds, st);
 }
 
 template <bool LOOP, int WAVES, int PREC>

@@ -263,7 +263,9 @@ __device__ __forceinline__ void load_ranges(const DevFrame& f, int bi, int h, in
 }
 
 // pre: ranges already loaded by the caller (load_ranges), or nullptr
-template <int BB, bool FAST = false>
+// COUNT: derive the sample count from the ranges (bundle_sampler.py:179); false leaves q.count to the caller (the dense schedule
+// reads it from the plan's sample list)
+template <int BB, bool FAST = false, bool COUNT = true>
 __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<BB>& q,
                                             const float* pre = nullptr) {
     constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
@@ -295,7 +297,7 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __re
     }
     if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }  // :224-226 (IEEE: feeds the sample count)
     q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
-    q.count = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
+    q.count = COUNT ? sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive) : 1;
 }
 
 template <int BB, bool FAST = false>

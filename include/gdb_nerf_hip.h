@@ -126,7 +126,11 @@ int gdb_pack_weights(const GdbConfig* cfg, const float* const h_tensors[18], flo
  * side (d_src_exts + d_src_ints, d_img_feat) may be NULL when only gdb_build_rays / gdb_sample follow.
  * The workspace also reserves room for the per-bundle
  * sample counts and their exclusive scan, which gdb_sample fills
- * (bundle_sampler.py:179,182-189). */
+ * (bundle_sampler.py:179,182-189).
+ * What gdb_prepare READS: the camera matrices, d_near_far, d_img_feat (and d_src_images in the _fpn form) - and, when the frame
+ * carries d_depth_range and the config is adaptive, THE CONTENTS OF d_depth_range AS THEY ARE AT THIS CALL, from which it builds
+ * the dense schedule's per-row plan and compacted sample list (gdb_dense_plan_layout / gdb_dense_map_layout).  A render call
+ * uses that plan only when told it is current (GDB_SCHED_PLAN_READY); otherwise it rebuilds it from the frame it is given. */
 int gdb_prepare(const GdbConfig* cfg, const GdbFrame* frame, void* d_workspace, size_t workspace_bytes,
                 void* stream);
 
