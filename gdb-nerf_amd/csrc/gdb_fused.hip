@@ -1755,12 +1755,12 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
     const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
     if (win >= krec[0]) return;  // (cannot happen with a plan that belongs to this depth prior)
-    // this window's bundles: first .. first + nb - 1, nb <= 32.  Everything read from the plan is clamped to the frame, so that a
-    // plan that does not belong to this frame's depth prior renders garbage instead of reading or writing outside the frame.
-    const int first = min(max(krec[1 + win], 0), f.W - 1);
-    const int nb = min(max(krec[2 + win] - first, 0), min(32, f.W - first));
-    if (nb <= 0) return;
-    const int L = f.planL, s0 = L * win;
+    // This window = the row's sample offsets [s0, s0 + n), n <= 32, whole bundles (plan_row).  Everything read from the plan is
+    // clamped to the frame, so that a plan that does not belong to this frame's depth prior renders garbage instead of reading or
+    // writing outside the frame.
+    const int s0 = min(max(krec[1 + win], 0), f.smapStride - 32);
+    const int n = min(max(krec[2 + win] - s0, 0), 32);
+    if (n <= 0) return;
     const unsigned m = ldu<unsigned>(f.smap + (size_t)rowid * f.smapStride, 4u * (unsigned)(s0 + j));  // lane j = sample s0 + j of the row
     float tc[TAR_STRIDE];
     {
@@ -1770,9 +1770,12 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
     }
     STAMP(0);
     const int mx = (int)(m & 0xFFFFu), k = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
+    // the window's bundles: first (lane 0's: a window starts at a bundle's first sample) .. the last lane's, nb <= 32
+    const int first = min(max(__builtin_amdgcn_readfirstlane(mx), 0), f.W - 1);
+    const int nb = min(max(__builtin_amdgcn_readlane(mx, n - 1) - first + 1, 0), min(32, f.W - first));
+    if (nb <= 0) return;
     const int bj = min(max(mx - first, 0), nb - 1);          // this sample's bundle inside the window (= its output column)
-    // a sample of this window: its bundle starts at an offset inside [s0, s0 + L)
-    const bool act = m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k >= 0 && j - k < L && k < mcnt && mcnt <= f.S_max;
+    const bool act = j < n && m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k >= 0 && k < mcnt && mcnt <= f.S_max;
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
     float z; float vox[4];

@@ -217,11 +217,21 @@ struct PrepArgs {
     unsigned* smap; int smapStride; int* nwin;
 };
 
-// One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, and for
-// every window of planL consecutive sample offsets the first bundle whose offset falls into it.  Row record: [number of windows,
-// first bundle of window 0 .. nwin-1, W].  Lane l takes the bundles [l * cpl, (l+1) * cpl) of the row.
-// Also the row's compacted sample list (WsLayout::smapOff): entry s = [bundle | slot << 16 | count << 24].
-__device__ void plan_row(const PrepArgs& a, int rowid, int lane) {
+// One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, the row's
+// compacted sample list (WsLayout::smapOff: entry s = [bundle | slot << 16 | count << 24], bundle-major / sample-minor as
+// bundle_sampler.py:182-189 orders it) and its cut into WINDOWS of whole bundles holding at most 32 samples each - one window = one
+// wave of k_render_dense, lane = sample.  Row record: [number of windows, first sample offset of window 0 .. nwin-1, total].
+// Lane l takes the bundles [l * cpl, (l+1) * cpl) of the row.
+//   * Greedy cut (rows of up to PLAN_LDS_ROW sample offsets): every window takes bundles until the next one would not fit, so a
+//     wave idles (count of the bundle that did not fit) - 1 lanes at most: ~97 % of the lanes carry a sample at S_max 3, ~94 % at 6.
+//     The cut is a chain - window w + 1 starts where window w ends - walked by one lane over a byte per sample offset in LDS
+//     (slot of the sample | 128 if it is its bundle's last): if the sample at start + 31 ends its bundle the next window starts at
+//     start + 32, else at that bundle's first sample.
+//   * Fixed cut (longer rows): window w = the bundles whose first sample offset falls into [planL w, planL (w + 1)), planL = 33 -
+//     S_max: needs no chain, fills (planL + ~1) / 32 of the lanes (round 2's plan).
+// Either way a row has at most planMW = ceil(W S_max / planL) windows.
+#define PLAN_LDS_ROW 5120
+__device__ void plan_row(const PrepArgs& a, int rowid, int lane, unsigned char* __restrict__ info) {
     const int bi = rowid / a.H, row = rowid % a.H;
     const float nr = a.near_far[bi * 2], fr = a.near_far[bi * 2 + 1];
     const float miniv = a.inv_depth ? (1.f / nr - 1.f / fr) / (float)a.gnd : (fr - nr) / (float)a.gnd;  // = T_MINIV of the camera block
@@ -246,19 +256,39 @@ __device__ void plan_row(const PrepArgs& a, int rowid, int lane) {
     if (lane == 0) cprev = 0;
     int* rec = a.plan + (size_t)rowid * (a.planMW + 2);
     unsigned* sm = a.smap + (size_t)rowid * a.smapStride;
+    const bool greedy = a.W * a.S_max <= PLAN_LDS_ROW;
     for (int s = total + lane; s < a.smapStride; s += 64) sm[s] = 0xFFFFFFFFu;  // past the row's last sample
     for (int x = x0; x < x1; ++x) {
         const int w = off / a.planL;
         const int c = count_at(x);
-        // the row's sample list: bundle-major, sample-minor (bundle_sampler.py:182-189)
-        for (int k = 0; k < c; ++k) sm[off + k] = (unsigned)x | ((unsigned)k << 16) | ((unsigned)c << 24);
-        // consecutive bundle offsets differ by at most S_max <= planL, so every window up to the one the LAST bundle starts in
-        // has a first bundle; windows beyond that one hold no bundle start (the last bundle's samples may reach into the next
-        // window of offsets — they still belong to the window the bundle starts in)
-        if (x == 0 || (off - cprev) / a.planL != w) rec[1 + w] = x;
-        if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = a.W; a.nwin[rowid] = w + 1; }
+        for (int k = 0; k < c; ++k) {
+            sm[off + k] = (unsigned)x | ((unsigned)k << 16) | ((unsigned)c << 24);
+            if (greedy) info[off + k] = (unsigned char)(k | (k == c - 1 ? 128 : 0));
+        }
+        if (!greedy) {
+            // consecutive bundle offsets differ by at most S_max <= planL, so every window up to the one the LAST bundle starts in
+            // has a first bundle; windows beyond that one hold no bundle start (the last bundle's samples may reach into the next
+            // window of offsets - they still belong to the window the bundle starts in)
+            if (x == 0 || (off - cprev) / a.planL != w) rec[1 + w] = off;
+            if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = off + c; a.nwin[rowid] = w + 1; }
+        }
         cprev = c;
         off += c;
+    }
+    if (greedy) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the bytes of all lanes are in LDS before lane 0 walks them
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {
+            int start = 0, w = 0;
+            while (start < total && w < a.planMW) {
+                rec[1 + w++] = start;
+                const int p = min(start + 32, total) - 1;       // the last sample 32 lanes could hold
+                const int e = info[p];
+                start = (p == total - 1 || (e & 128)) ? p + 1 : p - (e & 127);   // whole bundles only: a cut bundle opens the next window
+            }
+            rec[0] = w; rec[1 + w] = total; a.nwin[rowid] = w;
+        }
     }
 }
 
@@ -272,6 +302,7 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
 
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
+    static_assert(sizeof(tile4) >= 4 * PLAN_LDS_ROW, "the plan rows borrow the tile's LDS");
     // Grid: [camera block | plan workgroups (4 bundle-map rows each) | pyramid tiles].  The serial pieces come FIRST: the camera
     // block is one short chain of fp64 inverses, a plan row one wave walking a latency chain (strided loads, IEEE divisions, a scan,
     // scattered stores); dispatched last they ran on after the tiles had drained (k_prepare 10.7 -> 13.7 us when every adaptive
@@ -284,7 +315,8 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     }
     if ((int)blockIdx.x <= a.nplan) {
         const int rowid = ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);
-        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
+        // (the plan rows borrow the tile's LDS: 4 rows x PLAN_LDS_ROW bytes = the 20 KB of tile4)
+        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, (unsigned char*)tile4 + (size_t)(threadIdx.x >> 6) * PLAN_LDS_ROW);
         return;
     }
     const int blk = (int)blockIdx.x - 1 - a.nplan;
@@ -363,8 +395,9 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
 
 // The dense plan alone (for a render call that asks for GDB_SCHED_DENSE on a frame whose prepare did not build it).
 __global__ void __launch_bounds__(256) k_plan(PrepArgs a) {
+    __shared__ unsigned char info[4 * PLAN_LDS_ROW];
     const int rowid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63);
+    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, info + (size_t)(threadIdx.x >> 6) * PLAN_LDS_ROW);
 }
 int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st) {
     WsLayout L = ws_layout(*cfg, *f);

@@ -323,8 +323,9 @@ class HotPathEngine:
         return res
 
     def dense_plan(self) -> torch.Tensor:
-        """The dense schedule's plan `prepare` built from the depth prior: (B*H, stride) int32, row = [n_windows, first bundle of
-        each window, W]; plus the window length L as `.window` attribute.  See include/gdb_nerf_hip.h gdb_dense_plan_layout."""
+        """The dense schedule's plan built from the depth prior: (B*H, stride) int32, row = [n_windows, first sample offset of each
+        window, the row's sample total]; plus L = 33 - S_max (the fixed-cut window length) as `.window` attribute.  See
+        include/gdb_nerf_hip.h gdb_dense_plan_layout."""
         f = self._need_frame()
         out = (C.c_size_t * 3)()
         _lib.check(self.lib.gdb_dense_plan_layout(C.byref(self.cfg), C.byref(f), out))

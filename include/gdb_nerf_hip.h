@@ -95,17 +95,19 @@ int gdb_workspace_bytes(const GdbConfig* cfg, const GdbFrame* shape, size_t* out
  * an odd extent), out[3 + l] = float offset of level l inside one pyramid, l = 0..3. */
 int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]);
 
-/* Where gdb_prepare() puts the plan of the dense schedule (GDB_SCHED_DENSE), for callers / tests that want to read it: per
- * bundle-map row (B*H rows) out[1] int32 values [n_windows, first bundle of window 0 .. n_windows-1, W]; a window is the run of
- * consecutive bundles whose first sample offset inside the row (exclusive prefix of the per-bundle sample counts,
- * bundle_sampler.py:179-189) falls into [out[2] * w, out[2] * (w + 1)) — at most 32 samples.  out[0] = byte offset of the
- * first row record.  Built by gdb_prepare FROM THE CONTENTS OF d_depth_range AT THAT TIME when the frame carries it and the
+/* Where the plan of the dense schedule (GDB_SCHED_DENSE) lives, for callers / tests that want to read it: per bundle-map row
+ * (B*H rows) out[1] int32 values [n_windows, first sample offset of window 0 .. n_windows-1, the row's sample total].  A window
+ * is a run of WHOLE consecutive bundles holding at most 32 samples (offsets = exclusive prefix of the per-bundle sample counts
+ * along the row, bundle_sampler.py:179-189) - one wave of the dense kernel, lane = sample.  Rows of up to 5120 sample offsets
+ * (W * S_max) are cut greedily (a window ends only where the next bundle would not fit); longer rows at fixed offsets: window w =
+ * the bundles whose first sample offset falls into [out[2] * w, out[2] * (w + 1)), out[2] = 33 - S_max.  out[0] = byte offset of
+ * the first row record.  Built by gdb_prepare FROM THE CONTENTS OF d_depth_range AT THAT TIME when the frame carries it and the
  * config is adaptive; a dense render that is not told the plan is current (GDB_SCHED_PLAN_READY) rebuilds it first. */
 int gdb_dense_plan_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[3]);
 /* ... and the compacted sample list beside it (bundle_sampler.py:182-189: bundle-major, sample-minor): per bundle-map row out[1]
  * uint32 entries, entry s = the sample at offset s of the row as [bundle x | slot k << 16 | count of the bundle << 24],
  * 0xFFFFFFFF past the row's last sample.  out[0] = byte offset of the first row.  Window w of the plan is the wave that reads
- * entries [L w, L w + 32) and keeps those whose bundle starts inside [L w, L (w + 1)). */
+ * the entries [start_w, start_{w+1}) of its row. */
 int gdb_dense_map_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[2]);
 
 /* ---- MLP weights -------------------------------------------------------------------- */

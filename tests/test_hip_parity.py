@@ -532,14 +532,16 @@ def test_split_f16_precision_is_relative(wscale, fscale):
 
 
 @pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),
-                                                          (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu")])
+                                                          (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu"),
+                                                          (8, 800, 1, 16, True, False, "dtu")])
 def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
-    """The plan of the dense schedule (k_prepare): for every bundle-map row the windows are consecutive, non-empty runs of
-    bundles covering the row, each holding at most 32 samples, and window w starts at the first bundle whose sample offset
-    (exclusive prefix of the oracle's per-bundle counts) reaches L * w."""
+    """The plan of the dense schedule (plan_row): for every bundle-map row the compacted sample list is the reference's
+    (bundle_sampler.py:182-189: bundle-major, sample-minor, from the oracle's per-bundle counts), and the windows cut it into
+    consecutive runs of WHOLE bundles of at most 32 samples that cover the row - greedily (a window ends only where the next
+    bundle would not fit) on rows of up to 5120 sample offsets, at fixed offsets L * w beyond (the last parameter set)."""
     frame = synthetic.make_frame(Ho, Wo, V=2, B=B, scene=scene, seed=17)
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=1), (3, 0), max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
-    eng.render()   # an explicit dense render builds the plan where prepare did not (fixed counts, S_max <= 3)
+    dense = [t.clone() for t in eng.render()]   # an explicit dense render builds the plan where prepare did not (fixed counts)
     H, W = Ho // 2, Wo // 2
     rays = oracle_rays(frame)
     smp = oracle.sample_bundles(rays, frame["depth_range"], frame["vol_range"], frame["near_far"][:, 0], frame["near_far"][:, 1], 2, S, 64,
@@ -548,15 +550,20 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
     plan = npy(eng.dense_plan())
     L = eng.dense_plan().window
     assert L == 33 - S
+    greedy = W * S <= 5120
     for r in range(B * H):
-        nwin = int(plan[r, 0])
-        firsts = plan[r, 1:2 + nwin]
-        assert firsts[0] == 0 and firsts[-1] == W and np.all(np.diff(firsts) > 0)
-        off = np.concatenate(([0], np.cumsum(cnt[r])[:-1]))
-        for w in range(nwin):
-            a, b = int(firsts[w]), int(firsts[w + 1])
-            assert cnt[r, a:b].sum() <= 32 and b - a <= 32
-            assert off[a] >= L * w and (a == 0 or off[a - 1] < L * w) and off[b - 1] < L * (w + 1)
+        nwin, tot = int(plan[r, 0]), int(cnt[r].sum())
+        starts = plan[r, 1:2 + nwin].astype(np.int64)      # first sample offset of every window, then the row's total
+        assert starts[0] == 0 and starts[-1] == tot and np.all(np.diff(starts) > 0) and np.all(np.diff(starts) <= 32)
+        off = np.concatenate(([0], np.cumsum(cnt[r])))       # sample offset of every bundle's first sample, then the total
+        assert np.all(np.isin(starts, off))                  # windows hold whole bundles
+        nxt = {int(o): int(c) for o, c in zip(off[:-1], cnt[r])}
+        for w in range(nwin - 1):
+            if greedy:   # the bundle that opens window w + 1 did not fit into window w
+                assert starts[w + 1] - starts[w] + nxt[int(starts[w + 1])] > 32
+            else:        # window w = the bundles whose first sample offset falls into [L w, L (w + 1))
+                assert L * w <= starts[w] < L * (w + 1) or w == 0
+                assert starts[w + 1] >= L * (w + 1)
     # the compacted sample list (bundle_sampler.py:182-189: bundle-major, sample-minor), row by row
     smap = npy(eng.dense_map())
     for r in range(B * H):
@@ -566,6 +573,10 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
         want = xs | (ks << 16) | (np.repeat(cnt[r], cnt[r]) << 24)
         assert np.array_equal(smap[r, :tot], want)
         assert np.all(smap[r, tot:] == 0xFFFFFFFF)
+    # and the render it drives agrees with the slot-wave schedule's
+    eng.set_schedule(1 if S <= 8 else 2)
+    for a, b in zip(dense, eng.render()):
+        assert max_abs(npy(a), npy(b)) <= 2e-5 * max(1.0, float(b.abs().max()))
 
 
 def test_dense_render_follows_a_depth_prior_changed_after_prepare():
