@@ -213,7 +213,13 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   GDB_PREC_F32X split-f16: every MFMA operand as an f16 pair hi + lo (about 22 bits), a product as lo·hi + hi·lo + hi·hi on
  *                 v_mfma_f32_32x32x16_f16 with fp32 accumulate — fp32-grade (not bit-exact fp32) at close to the f16 rate.
  *                 Like GDB_PREC_F16 it assumes activations inside the f16 range: the high half saturates at 65504 (the low
- *                 half then carries the rest up to about twice that; beyond it the value is clipped).
+ *                 half then carries the rest up to about twice that; beyond it the value is clipped).  Operand range of the
+ *                 "22 bits": the low half of a value below 2^-3 is an f16 subnormal (resolution 2^-24), so a pair carries an
+ *                 ABSOLUTE error floor of 2^-25 per operand: |x| >= 0.125 keeps ~22 bits, |x| = 1e-3 about 15, and below 6e-5
+ *                 the high half is subnormal too (plain f16 accuracy).  Measured on the MLP with every weight scaled (profiles/
+ *                 r03/split_f16_small_operands.txt): |f32x - f32| / output scale 5e-7 at x1, 1.5e-6 at x0.2, 5e-6 at x0.05,
+ *                 3e-5 at x0.01, 2e-4 (= GDB_PREC_F16's) at x0.001.  Weights are not rescaled at pack time: use GDB_PREC_F32 for
+ *                 checkpoints with layers of such small magnitude.
  * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list

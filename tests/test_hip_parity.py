@@ -515,9 +515,9 @@ def test_split_f16_precision_tracks_fp32(H, W, V, S, adaptive):
 
 @pytest.mark.parametrize("wscale,fscale", [(1.0, 1.0), (3.0, 1.0), (0.2, 8.0), (2.0, 30.0)])
 def test_split_f16_precision_is_relative(wscale, fscale):
-    """The split keeps ~22 bits of every operand whatever its magnitude (inside the f16 range): with the MLP weights and the
+    """The split keeps ~22 bits of every operand of magnitude >= 2^-3 (and inside the f16 range): with the MLP weights and the
     image features scaled, |f32x - f32| stays a few 1e-7 of the output's scale.  (Activations reach a few hundred at the last
-    pair of scales; f16 operands lose three more digits there.)"""
+    pair of scales; f16 operands lose three more digits there.)  Small operands: test_split_f16_small_operands_have_an_absolute_floor."""
     frame = synthetic.make_frame(96, 128, V=3, B=1, seed=5)
     frame["img_feat"] = (frame["img_feat"] * np.float32(fscale)).astype(np.float32)
     w = {k: (v * np.float32(wscale)).astype(np.float32) for k, v in synthetic.make_nerf_weights(seed=8).items()}
@@ -529,6 +529,21 @@ def test_split_f16_precision_is_relative(wscale, fscale):
     ex, eh = max_abs(npy(x), npy(ref)) / scale, max_abs(npy(h), npy(ref)) / scale
     print(f"weights x{wscale}, features x{fscale}: output scale {scale:.3g}, |f32x - f32| / scale {ex:.2e}, |f16 - f32| / scale {eh:.2e}")
     assert np.isfinite(npy(x)).all() and ex <= 5e-6 and ex * 30 <= max(eh, 1e-5)   # (observed 1.8e-7 .. 2.4e-6; the softmax scores grow with the scales)
+
+
+@pytest.mark.parametrize("wscale,bound", [(0.2, 5e-6), (0.05, 2e-5), (0.01, 1e-4)])
+def test_split_f16_small_operands_have_an_absolute_floor(wscale, bound):
+    """The documented operand range of GDB_PREC_F32X (include/gdb_nerf_hip.h): the low half of a value below 2^-3 is an f16
+    subnormal, so small weights keep fewer than 22 bits - the error of the pure-MLP outputs (the 8 feat_head channels) over their
+    scale grows as the weights shrink (measured 1.5e-6 / 5e-6 / 3e-5), while staying below the plain f16 path's."""
+    frame = synthetic.make_frame(96, 128, V=3, B=1, seed=5)
+    w = {k: (v * np.float32(wscale)).astype(np.float32) for k, v in synthetic.make_nerf_weights(seed=8).items()}
+    eng = engine_for(frame, w, max_num_samples=4, is_adaptive=True)
+    ref, x, h = (eng.render(precision=p)[0][:, 31:39].clone() for p in (1, 2, 0))
+    scale = float(ref.abs().max())
+    ex, eh = max_abs(npy(x), npy(ref)) / scale, max_abs(npy(h), npy(ref)) / scale
+    print(f"weights x{wscale}: feat_head scale {scale:.3g}, |f32x - f32| / scale {ex:.2e}, |f16 - f32| / scale {eh:.2e}")
+    assert ex <= bound and ex <= eh
 
 
 @pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),

@@ -44,10 +44,20 @@ def child(cases, steps):
                 eng.render(out=o)
             torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            eng.render(out=o)
-        e1.record(); torch.cuda.synchronize()
+        if os.environ.get("AB_WITH_PREPARE"):   # the bench step: prepare + render, frames cycled through an HBM ring
+            ring = [frames[wl_name]] + [{k: v.clone() for k, v in frames[wl_name].items()} for _ in range(6)]
+            for i in range(50):
+                eng.prepare(ring[i % 7]); eng.render(out=o)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(steps):
+                eng.prepare(ring[i % 7]); eng.render(out=o)
+            e1.record(); torch.cuda.synchronize()
+        else:
+            e0.record()
+            for _ in range(steps):
+                eng.render(out=o)
+            e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / steps * 1e3
         ref = eng.render_unfused()[0]
         err = float((o[0] - ref).abs().max())

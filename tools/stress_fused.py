@@ -29,6 +29,18 @@ for i in range(N):
                 bad += 1
                 print(f"FAIL case {i} {Ho}x{Wo} {c} schedule {sched} precision {prec}: bundle_feat err {e:.3e}, opacity err {eo:.3e}", flush=True)
     eng.set_schedule(0)
+    # GDB_SCHED_AUTO, packed rows, two row strips cut at a random row against the whole frame: bit for bit (the multi-GPU unit)
+    H = Ho // 2
+    full = eng.render_packed(precision=1).clone()
+    cut = int(rng.integers(0, H + 1))
+    part = torch.full_like(full, float("nan"))
+    eng.render_packed(0, cut, 1, part); eng.render_packed(cut, H, 1, part)
+    if not torch.equal(full, part):
+        bad += 1
+        print(f"FAIL case {i} {Ho}x{Wo} {c}: row strips [0,{cut}) + [{cut},{H}) differ from the full frame", flush=True)
+    if not (np.abs(full[:, :39].cpu().numpy() - ubf).max() <= 1e-3):
+        bad += 1
+        print(f"FAIL case {i} {Ho}x{Wo} {c}: packed AUTO render off the fp32 chain", flush=True)
     if i % 50 == 49: print(f"{i + 1} cases, worst err so far {worst:.3e}, failures {bad}", flush=True)
 print(f"done: {N} cases x 3 schedules x 3 precisions, worst fp32-grade bundle_feat err {worst:.3e}, failures {bad}")
 sys.exit(1 if bad else 0)
