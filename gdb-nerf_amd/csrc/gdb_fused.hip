@@ -918,12 +918,13 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     f32x16 base;
     Frag<X> a_view, a_ga0, a_ga1;
     f32x16 w_agg;
-    {   LANE_KEYS();  // mean / unbiased variance of g_v over views (Welford)   nerf.py:73
+    {   LANE_KEYS();  // mean / unbiased variance of g_v over views   nerf.py:73
         a_view = load_fragx<X>(mf, F_VIEW, lane_o);
         const Frag<X> gv0 = load_fragx<X>(mf, F_GVAR, lane_o), gv1 = load_fragx<X>(mf, F_GVAR + 1, lane_o);
         const Frag<X> gm0 = load_fragx<X>(mf, F_GMEAN, lane_o), gm1 = load_fragx<X>(mf, F_GMEAN + 1, lane_o);
         a_ga0 = load_fragx<X>(mf, F_GA, lane_o); a_ga1 = load_fragx<X>(mf, F_GA + 1, lane_o);  // next phase
         w_agg = load_tab(mf, TD_AGG, h_o);
+        // sum and sum of squares (var = (sum g^2 - V mean^2) / (V - 1)): two instructions per value and view, Welford's update four
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
@@ -931,17 +932,16 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
         for (int v = 0; v < V; ++v) {
             const Tail<X> tl = load_tail<X>(stage + (size_t)v * STAGE_V, j, h);
             f32x16 g = view_g<X>(tl, a_view);
-            float inv = frcp((float)(v + 1));
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                float d = g[i] - mean[i];
-                mean[i] = fmaf(d, inv, mean[i]);
-                m2[i] = fmaf(d, g[i] - mean[i], m2[i]);
-            }
+            for (int i = 0; i < 12; ++i) { mean[i] += g[i]; m2[i] = fmaf(g[i], g[i], m2[i]); }
         }
-        float iv = frcp((float)(V - 1));
+        const float rv = frcp((float)V), iv = frcp((float)(V - 1));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m2[i] = m2[i] * iv;
+        for (int i = 0; i < 12; ++i) {
+            const float s1 = mean[i];
+            mean[i] = s1 * rv;
+            m2[i] = (m2[i] - s1 * mean[i]) * iv;
+        }
         m2[12] = 1.f;  // spare slot 24 of the variance operand: constant one that carries global_fc's bias
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
         base = mm<X>(gv0, accf<0, false, X>(m2), zero16());
