@@ -221,74 +221,104 @@ struct PrepArgs {
 // compacted sample list (WsLayout::smapOff: entry s = [bundle | slot << 16 | count << 24], bundle-major / sample-minor as
 // bundle_sampler.py:182-189 orders it) and its cut into WINDOWS of whole bundles holding at most 32 samples each - one window = one
 // wave of k_render_dense, lane = sample.  Row record: [number of windows, first sample offset of window 0 .. nwin-1, total].
-// Lane l takes the bundles [l * cpl, (l+1) * cpl) of the row.
-//   * Greedy cut (rows of up to PLAN_LDS_ROW sample offsets): every window takes bundles until the next one would not fit, so a
+// The row is walked in rounds of 64 bundles, one per lane.
+//   * Greedy cut (rows of PLAN_GREEDY_MIN .. PLAN_LDS_ROW - 1 sample offsets): every window takes bundles until the next one would not fit, so a
 //     wave idles (count of the bundle that did not fit) - 1 lanes at most: ~97 % of the lanes carry a sample at S_max 3, ~94 % at 6.
-//     The cut is a chain - window w + 1 starts where window w ends - walked by one lane over a byte per sample offset in LDS
-//     (slot of the sample | 128 if it is its bundle's last): if the sample at start + 31 ends its bundle the next window starts at
-//     start + 32, else at that bundle's first sample.
-//   * Fixed cut (longer rows): window w = the bundles whose first sample offset falls into [planL w, planL (w + 1)), planL = 33 -
+//     The cut is a chain - window w + 1 starts at the last bundle start within 32 offsets of window w's - and it sits on
+//     k_prepare's critical path, so it is walked in SCALAR code over a bit per sample offset (1 = a bundle starts here; OR-ed into
+//     LDS words by the lanes, then held one word per lane): a hop is two v_readlane, a 64-bit shift and a find-last-bit, ~70 cycles
+//     (a byte per offset in LDS read by one lane: ~180 per hop, 2.2 us of k_prepare on c2).
+//   * Fixed cut (shorter and longer rows): window w = the bundles whose first sample offset falls into [planL w, planL (w + 1)), planL = 33 -
 //     S_max: needs no chain, fills (planL + ~1) / 32 of the lanes (round 2's plan).
 // Either way a row has at most planMW = ceil(W S_max / planL) windows.
-#define PLAN_LDS_ROW 5120
-__device__ void plan_row(const PrepArgs& a, int rowid, int lane, unsigned char* __restrict__ info) {
+#ifndef PLAN_GREEDY_MIN
+#define PLAN_GREEDY_MIN 1024
+#endif
+#ifndef PLAN_LDS_ROW
+#define PLAN_LDS_ROW 4096   // sample offsets of a row the greedy cut handles: 128 words of start bits, two per lane
+#endif
+__device__ void plan_row(const PrepArgs& a, int rowid, int lane, unsigned* __restrict__ words) {
     const int bi = rowid / a.H, row = rowid % a.H;
     const float nr = a.near_far[bi * 2], fr = a.near_far[bi * 2 + 1];
     const float miniv = a.inv_depth ? (1.f / nr - 1.f / fr) / (float)a.gnd : (fr - nr) / (float)a.gnd;  // = T_MINIV of the camera block
     const size_t hw = (size_t)a.H * a.W;
     const float* nearp = a.depth_range + ((size_t)bi * 2) * hw + (size_t)row * a.W;
     const float* farp = nearp + hw;
-    const int cpl = (a.W + 63) / 64;
-    const int x0 = lane * cpl, x1 = min(a.W, x0 + cpl);
-    auto count_at = [&](int x) {
-        float n0 = nearp[x], f0 = farp[x];
-        if (a.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }  // bundle_sampler.py:224-226, as load_bundle does
-        return sample_count(n0, f0, miniv, a.S_max, a.adaptive);
-    };
-    int sum = 0, lastc = 0;
-    for (int x = x0; x < x1; ++x) { lastc = count_at(x); sum += lastc; }
-    int incl = sum;  // inclusive prefix over lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, 63);
-    int off = incl - sum;                       // sample offset of this lane's first bundle
-    int cprev = __shfl_up(lastc, 1);            // count of the bundle just before it
-    if (lane == 0) cprev = 0;
     int* rec = a.plan + (size_t)rowid * (a.planMW + 2);
     unsigned* sm = a.smap + (size_t)rowid * a.smapStride;
-    const bool greedy = a.W * a.S_max <= PLAN_LDS_ROW;
-    for (int s = total + lane; s < a.smapStride; s += 64) sm[s] = 0xFFFFFFFFu;  // past the row's last sample
-    for (int x = x0; x < x1; ++x) {
-        const int w = off / a.planL;
-        const int c = count_at(x);
-        for (int k = 0; k < c; ++k) {
+    // The greedy chain costs ~0.1 us per window of the row on k_prepare's critical path (c2: +2.5 us) and saves idle lanes in the
+    // render (c2, 960 sample offsets per row, S_max 3: 1 us; c3, 1440: 9 us; c4, 2400, S_max 6: 23 us): taken from 1024 offsets up.
+    const bool greedy = a.W * a.S_max < PLAN_LDS_ROW && a.W * a.S_max >= PLAN_GREEDY_MIN;
+    if (greedy) { words[lane] = 0u; words[64 + lane] = 0u; __builtin_amdgcn_wave_barrier(); }
+    // Rounds of 64 consecutive bundles, one per lane (coalesced loads and stores).  The row is ONE latency chain inside k_prepare,
+    // so the ranges of the first PLAN_PRE rounds (512 bundles) are all requested up front: under k_prepare's pyramid traffic a
+    // memory round trip costs microseconds, and the row pays one of them, not one per round.  (Measured, k_prepare on c2 with the
+    // fixed cut: 12.9 us with a chain of dependent loads, 11.8 us this way; 14.5 us with cpl consecutive bundles per lane and a
+    // single scan - strided loads, longer divergent store loops.)
+    int base = 0, cprev_carry = 0;   // samples before this round; count of the bundle just before it
+    constexpr int PLAN_PRE = 8;
+    float npre[PLAN_PRE], fpre[PLAN_PRE];
+#pragma unroll
+    for (int r = 0; r < PLAN_PRE; ++r) {
+        const int x = 64 * r + lane;
+        npre[r] = 0.f; fpre[r] = 0.f;
+        if (x < a.W) { npre[r] = nearp[x]; fpre[r] = farp[x]; }
+    }
+    for (int c0 = 0; c0 < a.W; c0 += 64) {
+        const int x = c0 + lane;
+        float n0 = 0.f, f0 = 0.f;
+        const int r = c0 >> 6;
+        if (r < PLAN_PRE) {
+#pragma unroll
+            for (int q = 0; q < PLAN_PRE; ++q) if (q == r) { n0 = npre[q]; f0 = fpre[q]; }
+        } else if (x < a.W) { n0 = nearp[x]; f0 = farp[x]; }
+        if (a.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }  // bundle_sampler.py:224-226, as load_bundle does
+        const int c = x < a.W ? sample_count(n0, f0, miniv, a.S_max, a.adaptive) : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int off = base + incl - c;            // sample offset of this lane's bundle
+        int cprev = __shfl_up(c, 1);                // count of the bundle just before it
+        if (lane == 0) cprev = cprev_carry;
+        for (int k = 0; k < c; ++k)                 // the row's sample list: bundle-major, sample-minor (bundle_sampler.py:182-189)
             sm[off + k] = (unsigned)x | ((unsigned)k << 16) | ((unsigned)c << 24);
-            if (greedy) info[off + k] = (unsigned char)(k | (k == c - 1 ? 128 : 0));
-        }
-        if (!greedy) {
+        if (greedy && x < a.W) atomicOr(&words[off >> 5], 1u << (off & 31));   // a bundle starts at offset `off`
+        if (!greedy && x < a.W) {
             // consecutive bundle offsets differ by at most S_max <= planL, so every window up to the one the LAST bundle starts in
             // has a first bundle; windows beyond that one hold no bundle start (the last bundle's samples may reach into the next
             // window of offsets - they still belong to the window the bundle starts in)
+            const int w = off / a.planL;
             if (x == 0 || (off - cprev) / a.planL != w) rec[1 + w] = off;
             if (x == a.W - 1) { rec[0] = w + 1; rec[2 + w] = off + c; a.nwin[rowid] = w + 1; }
         }
-        cprev = c;
-        off += c;
+        base += __shfl(incl, 63);
+        cprev_carry = __shfl(c, 63);
     }
+    const int total = base;
+    for (int s = total + lane; s < a.smapStride; s += 64) sm[s] = 0xFFFFFFFFu;  // past the row's last sample
     if (greedy) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the bytes of all lanes are in LDS before lane 0 walks them
+        if (lane == 0) atomicOr(&words[total >> 5], 1u << (total & 31));   // sentinel: the row ends where a bundle would start
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every lane's bits are in LDS before the words are read back
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0) {
-            int start = 0, w = 0;
-            while (start < total && w < a.planMW) {
-                rec[1 + w++] = start;
-                const int p = min(start + 32, total) - 1;       // the last sample 32 lanes could hold
-                const int e = info[p];
-                start = (p == total - 1 || (e & 128)) ? p + 1 : p - (e & 127);   // whole bundles only: a cut bundle opens the next window
-            }
-            rec[0] = w; rec[1 + w] = total; a.nwin[rowid] = w;
+        const unsigned w_lo = words[lane], w_hi = words[64 + lane];      // lane i holds words i and 64 + i of the row's start bits
+        auto word = [&](int i) -> unsigned {                              // wave-uniform i
+            const unsigned lo = __builtin_amdgcn_readlane(w_lo, i & 63), hi = __builtin_amdgcn_readlane(w_hi, i & 63);
+            return i < 64 ? lo : (i < 128 ? hi : 0u);
+        };
+        int start = 0, w = 0;
+        const int tot = __builtin_amdgcn_readfirstlane(total);
+        while (start < tot && w < a.planMW) {
+            if (lane == 0) rec[1 + w] = start;
+            ++w;
+            // the next window starts at the LAST bundle start among the offsets start + 1 .. start + 32 (bundles hold <= 16
+            // samples, so there is one; the sentinel ends the row)
+            const int q = start + 1, idx = q >> 5, sh = q & 31;
+            const unsigned long long both = ((unsigned long long)word(idx + 1) << 32) | word(idx);
+            const unsigned bits = (unsigned)(both >> sh);
+            start = __builtin_amdgcn_readfirstlane(q + 31 - __builtin_clz(bits | 1u));
         }
+        if (lane == 0) { rec[0] = w; rec[1 + w] = total; a.nwin[rowid] = w; }
     }
 }
 
@@ -302,7 +332,7 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
 
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
-    static_assert(sizeof(tile4) >= 4 * PLAN_LDS_ROW, "the plan rows borrow the tile's LDS");
+    static_assert(sizeof(tile4) >= 4 * 128 * sizeof(unsigned) && PLAN_LDS_ROW <= 128 * 32, "the plan rows borrow the tile's LDS: 128 words of start bits per row");
     // Grid: [camera block | plan workgroups (4 bundle-map rows each) | pyramid tiles].  The serial pieces come FIRST: the camera
     // block is one short chain of fp64 inverses, a plan row one wave walking a latency chain (strided loads, IEEE divisions, a scan,
     // scattered stores); dispatched last they ran on after the tiles had drained (k_prepare 10.7 -> 13.7 us when every adaptive
@@ -315,8 +345,8 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     }
     if ((int)blockIdx.x <= a.nplan) {
         const int rowid = ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);
-        // (the plan rows borrow the tile's LDS: 4 rows x PLAN_LDS_ROW bytes = the 20 KB of tile4)
-        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, (unsigned char*)tile4 + (size_t)(threadIdx.x >> 6) * PLAN_LDS_ROW);
+        // (the plan rows borrow the tile's LDS: 128 words of bundle-start bits per row)
+        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, (unsigned*)tile4 + (size_t)(threadIdx.x >> 6) * 128);
         return;
     }
     const int blk = (int)blockIdx.x - 1 - a.nplan;
@@ -395,9 +425,9 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
 
 // The dense plan alone (for a render call that asks for GDB_SCHED_DENSE on a frame whose prepare did not build it).
 __global__ void __launch_bounds__(256) k_plan(PrepArgs a) {
-    __shared__ unsigned char info[4 * PLAN_LDS_ROW];
+    __shared__ unsigned words[4 * 128];
     const int rowid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, info + (size_t)(threadIdx.x >> 6) * PLAN_LDS_ROW);
+    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, words + (size_t)(threadIdx.x >> 6) * 128);
 }
 int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st) {
     WsLayout L = ws_layout(*cfg, *f);

@@ -98,8 +98,8 @@ int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7
 /* Where the plan of the dense schedule (GDB_SCHED_DENSE) lives, for callers / tests that want to read it: per bundle-map row
  * (B*H rows) out[1] int32 values [n_windows, first sample offset of window 0 .. n_windows-1, the row's sample total].  A window
  * is a run of WHOLE consecutive bundles holding at most 32 samples (offsets = exclusive prefix of the per-bundle sample counts
- * along the row, bundle_sampler.py:179-189) - one wave of the dense kernel, lane = sample.  Rows of up to 5120 sample offsets
- * (W * S_max) are cut greedily (a window ends only where the next bundle would not fit); longer rows at fixed offsets: window w =
+ * along the row, bundle_sampler.py:179-189) - one wave of the dense kernel, lane = sample.  Rows of 1024 .. 4095 sample offsets
+ * (W * S_max) are cut greedily (a window ends only where the next bundle would not fit); shorter and longer rows at fixed offsets: window w =
  * the bundles whose first sample offset falls into [out[2] * w, out[2] * (w + 1)), out[2] = 33 - S_max.  out[0] = byte offset of
  * the first row record.  Built by gdb_prepare FROM THE CONTENTS OF d_depth_range AT THAT TIME when the frame carries it and the
  * config is adaptive; a dense render that is not told the plan is current (GDB_SCHED_PLAN_READY) rebuilds it first. */

@@ -548,12 +548,12 @@ def test_split_f16_small_operands_have_an_absolute_floor(wscale, bound):
 
 @pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),
                                                           (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu"),
-                                                          (8, 800, 1, 16, True, False, "dtu")])
+                                                          (8, 800, 1, 16, True, False, "dtu"), (16, 960, 1, 3, True, False, "llff"), (8, 800, 1, 6, True, False, "nerf")])
 def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
     """The plan of the dense schedule (plan_row): for every bundle-map row the compacted sample list is the reference's
     (bundle_sampler.py:182-189: bundle-major, sample-minor, from the oracle's per-bundle counts), and the windows cut it into
     consecutive runs of WHOLE bundles of at most 32 samples that cover the row - greedily (a window ends only where the next
-    bundle would not fit) on rows of up to 5120 sample offsets, at fixed offsets L * w beyond (the last parameter set)."""
+    bundle would not fit) on rows of 1024 .. 4095 sample offsets (W * S_max), at fixed offsets L * w on shorter and longer ones."""
     frame = synthetic.make_frame(Ho, Wo, V=2, B=B, scene=scene, seed=17)
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=1), (3, 0), max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
     dense = [t.clone() for t in eng.render()]   # an explicit dense render builds the plan where prepare did not (fixed counts)
@@ -565,7 +565,7 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
     plan = npy(eng.dense_plan())
     L = eng.dense_plan().window
     assert L == 33 - S
-    greedy = W * S <= 5120
+    greedy = 1024 <= W * S < 4096
     for r in range(B * H):
         nwin, tot = int(plan[r, 0]), int(cnt[r].sum())
         starts = plan[r, 1:2 + nwin].astype(np.int64)      # first sample offset of every window, then the row's total
