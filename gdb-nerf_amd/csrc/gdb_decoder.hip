@@ -100,6 +100,22 @@ static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
                         }
 }
 
+// A layer of at most 32 output channels for k_conv16 (v_mfma_f32_16x16x4_f32: 16 output rows x 16 pixels x 4 input channels per
+// instruction, the same FLOP rate as the 32x32x2 form): [chunk][tap 9][g 8][lane 64][2] floats; element mt of lane l =
+// W[16 mt + (l & 15)][32 chunk + 4 g + (l >> 4)][tap] - the lane supplies A[row l & 15][k = l >> 4] of output tile mt.  Same size as
+// pack_conv's one-tile form.
+static void pack_conv16(const float* w, int cout, int cin, float* out) {
+    const int nchunk = (cin + 31) / 32;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int g = 0; g < 8; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int co = 16 * mt + (l & 15), ci = 32 * ch + 4 * g + (l >> 4);
+                        out[((((size_t)ch * 9 + tap) * 8 + g) * 64 + l) * 2 + mt] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                    }
+}
+
 // The same layer as split-f16 A-operand fragments of v_mfma_f32_32x32x16_f16: [tile NT][16-channel chunk][tap 9][hi, lo][lane 64][8
 // halfs]; element e of lane (i, h) = W[32 tile + i][16 chunk + 8 h + e][tap], hi = f16(w), lo = f16(w - hi).  The chunk count is
 // padded to an even number, so the size in floats equals pack_conv's.
@@ -151,8 +167,8 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
     memcpy(out + L.in_b, t[1], sizeof(float) * DEC_NF);
     for (int b = 0; b < num_layers; ++b) {
         const float* const* q = t + 2 + 5 * b;
-        pack_conv(q[0], DEC_G, DEC_NF, 1, out + L.blk[b][0]);
-        pack_conv(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blk[b][1]);
+        pack_conv16(q[0], DEC_G, DEC_NF, out + L.blk[b][0]);
+        pack_conv16(q[1], DEC_G, DEC_NF + DEC_G, out + L.blk[b][1]);
         pack_conv(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blk[b][2]);
         pack_conv_x(q[0], DEC_G, DEC_NF, 1, out + L.blkx[b][0]);
         pack_conv_x(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blkx[b][1]);
@@ -176,7 +192,7 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
             for (int k = 0; k < DEC_NF; ++k) acc += (double)wout[o * DEC_NF + k] * (double)bup[4 * k + s];
             out[L.up_b + 3 * s + o] = (float)acc;
         }
-    pack_conv(wf.data(), 12, DEC_NF, 1, out + L.up_w);
+    pack_conv16(wf.data(), 12, DEC_NF, out + L.up_w);
     pack_conv_x(wf.data(), 12, DEC_NF, 1, out + L.up_wx);
     return GDB_OK;
 }
@@ -335,6 +351,128 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
             }
         } else {
             *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;   // all buffers: strides and offsets multiples of 4
+            if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
+        }
+    }
+}
+
+
+// Layers of at most 32 output channels (conv1, conv2 of a dense block; the folded up stage with its 12) on v_mfma_f32_16x16x4_f32.
+// The 32x32x2 kernel above gives such a layer 2,560 equal waves for 1,024 SIMDs on a 256x320 map - half the SIMDs run three of them,
+// half two, and the layer takes three units of time for 2.5 units of work - and the 12-channel up stage wastes 20 of its 32 MFMA rows.
+// Here a wave is 16 pixels x MT tiles of 16 output channels (two accumulators of four registers), a workgroup 2 rows x 2 pixel
+// halves: 5,120 waves = five per SIMD, and the up stage (MT = 1) pays for 16 rows.  Staging is the 32x32x2 kernel's (rows + halo of a
+// 32-channel chunk in LDS, pixel stride 34 floats: lane l reads channel 4 g + (l >> 4) of pixel l & 15, 64 distinct banks); a B
+// operand is one ds_read_b32 and feeds MT MFMAs; weights stream from L2 as one float2 per lane and k-group (pack_conv16).
+template <int MT>
+__global__ void __launch_bounds__(256) k_conv16(ConvArgs a) {
+    constexpr int TR = 2;        // rows per workgroup
+    float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, kq = lane >> 4;
+    const int wrow = wid >> 1, ph = wid & 1;   // this wave's row of the workgroup and 16-pixel half of the column
+    const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
+    const int x0 = bx * 32, y0 = by * TR;
+    F4 acc[MT];   // D layout: register r of lane l = output row 4 (l >> 4) + r of pixel l & 15
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 16 * mt + 4 * kq + r;
+            acc[mt][r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+        }
+    const size_t img = (size_t)b * a.H * a.W;
+    // staging plan: as k_conv3x3 (slots fixed per thread, branch-free loads one chunk ahead)
+    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
+    int soff[NSLOT], loff[NSLOT];
+    unsigned inimg = 0;
+    const int g4 = 4 * (tid & 7);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int idx = tid + 256 * s;
+        const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
+        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
+        const bool slot = idx < (TR + 2) * DEC_PX * 8;
+        loff[s] = slot ? p * DEC_CHS + g4 : -1;
+        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
+        inimg |= (in ? 1u : 0u) << s;
+        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
+    }
+    const float* inb = a.in + img * a.in_stride;
+    const float* wbase = a.w + (size_t)lane * 2;
+    const float* brow = lds + (size_t)(wrow * DEC_PX + 16 * ph + pl) * DEC_CHS + kq;
+    F4 pre[NSLOT];
+    auto fetch = [&](int ch) {
+        const int ci = 32 * ch + g4;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (a.vec) pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
+            }
+        }
+    };
+    fetch(0);
+    F2 wn[8];   // the next tap's weights, loaded while the current tap's MFMAs run
+#pragma unroll
+    for (int g = 0; g < 8; ++g) wn[g] = *(const F2*)(wbase + (size_t)g * 128);
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (loff[s] < 0) continue;
+            const int ci = 32 * ch + g4;
+            const bool in = (inimg >> s) & 1;
+            F4 v = pre[s];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (in && (a.vec ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+            F2* dst = (F2*)(lds + loff[s]);
+            dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
+        }
+        __syncthreads();
+        if (ch + 1 < a.nchunk) fetch(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            F2 w[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) w[g] = wn[g];
+            {   // (the last prefetch of a layer reads the packed buffer's next layer / tail padding: in bounds, never used)
+                const float* wnext = wbase + ((size_t)ch * 9 + tap + 1) * 8 * 128;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) wn[g] = *(const F2*)(wnext + (size_t)g * 128);
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float bv = brow[(size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * g];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][0], bv, acc[0], 0, 0, 0);
+                if (MT > 1) acc[MT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][1], bv, acc[MT - 1], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane (pl, kq) holds output channels 16 mt + 4 kq + (0..3) of pixel (y0 + wrow, x0 + 16 ph + pl)
+    const int x = x0 + 16 * ph + pl, y = y0 + wrow;
+    if (x >= a.W || y >= a.H) return;
+    const size_t pix = img + (size_t)y * a.W + x;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = 16 * mt + 4 * kq;
+        if (co >= a.cout) continue;
+        F4 v = acc[mt];
+        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
+            const int Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = co + k;
+                if (c < 12) {
+                    const int sp = c / 3, o = c - 3 * sp;
+                    a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (sp >> 1)) * Wo + 2 * x + (sp & 1)] = v[k];
+                }
+            }
+        } else {
+            *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
             if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
         }
     }
@@ -580,6 +718,13 @@ static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int MT>
+static hipError_t launch_conv16(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
+    hipLaunchKernelGGL((k_conv16<MT>), dim3((unsigned)(a.B * a.tilesX * a.tilesY)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 static hipError_t launch_convx(const ConvArgs& a, int nt, hipStream_t st) {
     const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 9 * 2 * 64 * 4);
     static std::atomic<unsigned long long> done{0};
@@ -626,8 +771,9 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
             a.tilesY = (H + 4 * DECX_ROWS - 1) / (4 * DECX_ROWS);
             return launch_convx(a, nt, st);
         }
-        a.tilesY = (H + 4 / nt - 1) / (4 / nt);
-        return nt == 2 ? launch_conv<2>(a, st) : launch_conv<1>(a, st);
+        if (nt == 2) { a.tilesY = (H + 1) / 2; return launch_conv<2>(a, st); }
+        a.tilesY = (H + 1) / 2;   // layers of <= 32 output channels: k_conv16, 2 rows x 2 pixel halves per workgroup
+        return a.cout > 16 ? launch_conv16<2>(a, st) : launch_conv16<1>(a, st);
     };
     hipError_t e;
 #define CK(x) do { e = (x); if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "decoder launch: %s", hipGetErrorString(e)); } while (0)

@@ -37,6 +37,24 @@ def _unpack_conv(packed, cout, cin, nt):
     return w.reshape(cout, cin, 3, 3)
 
 
+def _unpack_conv16(packed, cout, cin):
+    """Inverse of pack_conv16 (layers of <= 32 output channels, v_mfma_f32_16x16x4_f32 operand order): [chunk][tap][g][lane][mt]
+    -> (cout, cin, 3, 3); element mt of lane l = W[16 mt + (l & 15)][32 chunk + 4 g + (l >> 4)][tap]."""
+    nchunk = (cin + 31) // 32
+    a = packed[:nchunk * 9 * 8 * 64 * 2].reshape(nchunk, 9, 8, 64, 2)
+    w = np.zeros((cout, cin, 9), np.float32)
+    for ch in range(nchunk):
+        for g in range(8):
+            for l in range(64):
+                for mt in range(2):
+                    co, ci = 16 * mt + (l & 15), 32 * ch + 4 * g + (l >> 4)
+                    if co < cout and ci < cin:
+                        w[co, ci, :] = a[ch, :, g, l, mt]
+                    else:
+                        assert np.all(a[ch, :, g, l, mt] == 0)
+    return w.reshape(cout, cin, 3, 3)
+
+
 def _unpack_conv_x(packed, cout, cin, nt):
     """Inverse of pack_conv_x: [tile][16-channel chunk][tap][hi, lo][lane][8 halfs] -> (hi, lo) each (cout, cin, 3, 3) as float32."""
     nchunk = (cin + 31) // 32 * 2
@@ -74,12 +92,12 @@ def test_packed_decoder_weights_and_the_folded_up_stage():
     assert np.array_equal(_unpack_conv(host[o:], 64, 27, 2), sd["in_conv.weight"]); o += conv_floats(27, 2)
     assert np.array_equal(host[o:o + 64], sd["in_conv.bias"]); o += 64
     for i in range(3):
-        assert np.array_equal(_unpack_conv(host[o:], 32, 64, 1), sd[f"blocks.{i}.conv1.weight"]); o += conv_floats(64, 1)
-        assert np.array_equal(_unpack_conv(host[o:], 32, 96, 1), sd[f"blocks.{i}.conv2.weight"]); o += conv_floats(96, 1)
+        assert np.array_equal(_unpack_conv16(host[o:], 32, 64), sd[f"blocks.{i}.conv1.weight"]); o += conv_floats(64, 1)
+        assert np.array_equal(_unpack_conv16(host[o:], 32, 96), sd[f"blocks.{i}.conv2.weight"]); o += conv_floats(96, 1)
         assert np.array_equal(_unpack_conv(host[o:], 64, 128, 2), sd[f"blocks.{i}.conv3.weight"]); o += conv_floats(128, 2)
         assert np.array_equal(host[o:o + 256].reshape(4, 64), sd[f"blocks.{i}.se.fc.0.weight"]); o += 256
         assert np.array_equal(host[o:o + 256].reshape(64, 4), sd[f"blocks.{i}.se.fc.2.weight"]); o += 256
-    wf = torch.from_numpy(_unpack_conv(host[o:], 12, 64, 1)); o += conv_floats(64, 1)
+    wf = torch.from_numpy(_unpack_conv16(host[o:], 12, 64)); o += conv_floats(64, 1)
     bf = torch.from_numpy(host[o:o + 12].copy())
     x = torch.randn(2, 64, 9, 11, generator=torch.Generator().manual_seed(0))
     want = F.conv2d(F.pixel_shuffle(F.conv2d(x, torch.from_numpy(sd["up.0.weight"]), torch.from_numpy(sd["up.0.bias"]), padding=1), 2),
@@ -98,7 +116,7 @@ def test_packed_decoder_weights_and_the_folded_up_stage():
     fp32["up"] = (q, 12, 64, 1)
     for key in ["in"] + [f"{i}{c}" for i in range(3) for c in ("c1", "c2", "c3")] + ["up"]:
         off, cout, cin, nt = fp32[key]
-        w = _unpack_conv(host[off:], cout, cin, nt)
+        w = _unpack_conv(host[off:], cout, cin, nt) if nt == 2 else _unpack_conv16(host[off:], cout, cin)
         hi, lo = _unpack_conv_x(host[o:], cout, cin, nt)
         assert np.array_equal(hi, w.astype(np.float16).astype(np.float32)), key
         assert np.all(np.abs(hi.astype(np.float64) + lo - w) <= np.abs(w) * 2.0 ** -21 + 2.0 ** -25), key
