@@ -46,6 +46,24 @@ def test_occupancy_the_schedules_are_designed_for(usage):
     """Registers per lane decide waves per SIMD (MI355X guide: <= 168 -> 3 waves, <= 256 -> 2): the one-slot-per-wave kernels
     run three waves per SIMD at all three precisions, and so does the dense kernel c2 / c3 / c4 take at fp32 and at f16
     (its split-f16 form is built in both a 3- and a 2-wave variant)."""
+    seen = set()
     for name, u in usage["gdb_fused.hip"].items():
-        if "k_render_fusedILb0ELi4E" in name or "k_render_denseILi1E" in name or "k_render_denseILi0ELi3E" in name or "k_render_denseILi2ELi3E" in name:
+        if ("k_render_fusedILb0ELi4E" in name or "k_render_denseILi1E" in name or "k_render_denseILi0ELi3E" in name or "k_render_denseILi2ELi3E" in name
+                or "k_render_soloILi0ELi3E" in name):   # (the last: the f16 segment-wave build c5 takes - V = 5 stages 17,280 B per wave, 9 waves per CU)
             assert u["vgprs"] <= 168 and u["waves_per_simd"] >= 3, (name, u)
+            seen.add(name.split("I")[0])
+    assert len(seen) >= 3, seen
+
+
+def test_staging_sizes_the_launcher_counts_on():
+    """LDS per wave (gdb_fused.hip stage_v<>): rows per view x 128 B.  f16: 27 rows (6 packed colour rows + 19 + 2 packed direction
+    rows), fp32 / split-f16: 35.  With 1280-byte LDS granules: V = 3 holds 12 waves per CU at every precision (two-wave workgroups
+    at fp32), V = 5 at f16 holds 9 (one-wave workgroups) - the numbers DESIGN.md quotes."""
+    gran, cap = 1280, 160 * 1024
+    waves = lambda lds, n: n * (cap // (-(-n * lds // gran) * gran))
+    f16, f32 = 27 * 128, 35 * 128
+    assert max(waves(3 * f32, 1), waves(3 * f32, 2)) == 12 and waves(3 * f32, 1) == 11
+    assert waves(3 * f16, 1) >= 12
+    assert waves(5 * f16, 1) == 9 and waves(5 * f32, 1) == 7
+    src = open(os.path.join(build.CSRC, "gdb_fused.hip")).read()
+    assert "PREC == GDB_PREC_F16 ? 6 : 12" in src and "GDB_CFR" in src   # row_feat<>: the layout the arithmetic above assumes
