@@ -313,8 +313,8 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 
 constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat ⊕ rgb
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
-// Per (wave, view) staging in LDS: 35 fp32 rows of 32 bundles — the reference's per-view vector
-// [rgbs 12 | feat ⊕ rgb 19 | dir 4] (bundle_sampler.py:369), one row per channel.
+// Per (wave, view) staging in LDS: rows of 32 bundles holding the reference's per-view vector [rgbs 12 | feat ⊕ rgb 19 | dir 4]
+// (bundle_sampler.py:369) - 35 fp32 rows, one per channel, at GDB_PREC_F32 / F32X; 27 rows at GDB_PREC_F16 (see row_feat<> below).
 // Timing-only ablation bits (GDB_FUSED_SKIP; 1 colours, 2 features, 4 volume, 8 MLP) exist only in the diagnostic build
 // -DGDB_DEBUG_SKIP: as runtime branches they split the gather into basic blocks and defeat its load scheduling.
 #ifdef GDB_DEBUG_SKIP
@@ -322,10 +322,8 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 #else
 #define SKIPPED(skip, bit) false
 #endif
-// The 4 direction values are only ever an f16 MFMA operand: they are staged as two rows of packed halves (dir0|dir1,
-// dir2|dir3) - the same rounding, just earlier - which makes a view 33 rows: three views are 12,672 B, under the 12,800 B
-// at which twelve one-wave workgroups fit a CU (the LDS allocation granule is 1280 B: tools/ubench/simd_map.hip).
-// (The f32 path stages the 4 direction values as fp32 rows: 35 rows.)
+// At GDB_PREC_F16 the 4 direction values are only ever an f16 MFMA operand: they are staged as two rows of packed halves
+// (dir0|dir1, dir2|dir3) - the same rounding, just earlier.  (The LDS allocation granule is 1280 B: tools/ubench/simd_map.hip.)
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
 // GDB_PREC_F16 goes one step further: the 12 sub-ray colours (values in [0, 1]) are staged as 6 rows of packed halves too (round
 // to nearest: 2.4e-4 at most, inside that path's 2e-3 bound), 27 rows = 3,456 B per view, so that five views (c5) are 17,280 B per
@@ -1659,14 +1657,13 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Dense schedule (GDB_SCHED_DENSE): the reference's flat, compacted sample list (bundle_sampler.py:182-189) cut into waves.
-// One wave = one window of a bundle-map row: the consecutive bundles whose first sample offset falls into [L w, L (w + 1)),
-// L = 33 - S_max, which together hold at most 32 samples.  The plan (plan_row: k_prepare or k_plan) names each window's first
-// bundle AND lists the row's samples in the reference's order, entry s = [bundle | slot | count]: the wave of window w reads
-// entries [L w, L w + 32) - lane j IS sample L w + j - and keeps those whose bundle starts inside the window (the first few
-// lanes may hold the tail of the previous window's last bundle: idle here, rendered there).  No per-wave count, scan or LDS map.
-// Lane (j, h): j = sample, h = half as everywhere.  Every lane carries a sample but for the window's edges, where the slot
-// schedules leave a lane idle whenever its bundle has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy,
-// c4 64 % -> 88 %.
+// One wave = one window of a bundle-map row: a run of whole consecutive bundles holding at most 32 samples.  The plan (plan_row:
+// k_prepare or k_plan) lists the row's samples in the reference's order, entry s = [bundle | slot | count], and cuts the row into
+// windows [start_w, start_{w+1}) - greedily (a window ends only where the next bundle would not fit) or at fixed offsets (window w
+// = the bundles whose first sample falls into [L w, L (w + 1)), L = 33 - S_max), see plan_row.  The wave of window w reads the
+// entries start_w + j: lane j IS that sample.  No per-wave count, scan or LDS map.
+// Lane (j, h): j = sample, h = half as everywhere.  Nearly every lane carries a sample, where the slot schedules leave a lane idle
+// whenever its bundle has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy, c4 64 % -> 94 %.
 // The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by looking
 // back over the earlier samples, the 22 weighted sums by a segmented suffix sum - for S_max <= 4 a Horner chain of DPP
 // wave shifts (acc <- v + next(acc): two VALU instructions per value and step, no LDS crossbar), beyond that log2(S_max)
