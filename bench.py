@@ -463,7 +463,10 @@ def main():
         try:
             import hashlib
             tj = json.load(open(tpath))
-            src_sha = hashlib.sha256(open(os.path.join(ROOT, "gdb-nerf_amd", "csrc", "gdb_fused.hip"), "rb").read()).hexdigest()[:16]
+            import re
+            src = open(os.path.join(ROOT, "gdb-nerf_amd", "csrc", "gdb_fused.hip"), encoding="utf-8").read()
+            code = "\n".join(l.rstrip() for l in re.sub(r"//[^\n]*", "", src).splitlines() if l.strip())   # (comments and blank lines do not change a kernel)
+            src_sha = hashlib.sha256(code.encode()).hexdigest()[:16]
             if tj.get("_kernel_source_sha256_16") == src_sha:
                 traffic = tj.get(f"{args.workload}:{kname}:{pname}")
                 tsrc = tj.get("_source")

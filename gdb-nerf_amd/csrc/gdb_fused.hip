@@ -1663,7 +1663,8 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
 // = the bundles whose first sample falls into [L w, L (w + 1)), L = 33 - S_max), see plan_row.  The wave of window w reads the
 // entries start_w + j: lane j IS that sample.  No per-wave count, scan or LDS map.
 // Lane (j, h): j = sample, h = half as everywhere.  Nearly every lane carries a sample, where the slot schedules leave a lane idle
-// whenever its bundle has fewer samples than the slot index: c2 80 % -> 92 % of the lanes busy, c4 64 % -> 94 %.
+// whenever its bundle has fewer samples than the slot index: c2 79.6 % of the slot lanes busy -> 92.2 % (fixed cut; greedy 95.6 %),
+// c3 79.6 -> 96.2 % (greedy), c4 (S_max 6) 44.4 -> 95.5 % (greedy; fixed cut 83.4 %).
 // The composite runs in registers across the lanes of a bundle (its samples are consecutive lanes): transmittance by looking
 // back over the earlier samples, the 22 weighted sums by a segmented suffix sum - for S_max <= 4 a Horner chain of DPP
 // wave shifts (acc <- v + next(acc): two VALU instructions per value and step, no LDS crossbar), beyond that log2(S_max)

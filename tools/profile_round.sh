@@ -39,7 +39,10 @@ print("fused kernel HBM traffic per launch (bytes):", res["traffic_bytes"])
 # traffic.json for bench.py's roofline.traffic, stamped with the kernel source it was measured on (bench.py refuses it otherwise)
 import hashlib
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
-sha = hashlib.sha256(open(os.path.join("$ROOT", "gdb-nerf_amd", "csrc", "gdb_fused.hip"), "rb").read()).hexdigest()[:16]
+import re
+src = open(os.path.join("$ROOT", "gdb-nerf_amd", "csrc", "gdb_fused.hip"), encoding="utf-8").read()
+code = "\n".join(l.rstrip() for l in re.sub(r"//[^\n]*", "", src).splitlines() if l.strip())   # comments and blank lines do not change a kernel
+sha = hashlib.sha256(code.encode()).hexdigest()[:16]
 tj = dict(res["traffic_bytes"])
 tj["_kernel_source_sha256_16"] = sha
 tj["_source"] = "profiles/$TAG/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, per launch: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; MI355X guide, HBM section)"
