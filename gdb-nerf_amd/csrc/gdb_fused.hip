@@ -1972,7 +1972,7 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
 #endif
     // Dense: the compacted sample list, one wave per <= 32 consecutive samples (needs the plan built from the depth prior).
     // Taken for adaptive counts, where the slot schedules leave lanes idle (c2, S_max 3: 80 % of the slot lanes busy, c4, S_max 6:
-    // 64 %).  Measured on MI355X (profiles/r03/schedules.txt), dense vs slot waves at f32: c2 103 vs 116 us, c3 183 vs 196,
+    // 44 %).  Measured on MI355X (profiles/r03/schedules.txt), dense vs slot waves at f32: c2 103 vs 116 us, c3 183 vs 196,
     // c3' 215 vs 240; f16 / split-f16 on c2: 56.3 vs 56.5, 70.1 vs 71.0 (round 2's dense schedule lost on c2: its per-wave
     // count / scan / LDS-map prologue, a ds_bpermute composite, and a grid with dead workgroups between live ones).
     const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && fr->W < 65536);
