@@ -1,0 +1,31 @@
+"""Soak: the fused kernel launched N times back to back per (workload, precision) under GDB_SCHED_AUTO, every 500th result compared bit
+for bit with the first (the round-1 corruption showed up only at full occupancy and only sometimes: DESIGN.md 4.1).
+usage: soak.py [N=30000]"""
+import os, sys, time, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from bench import WORKLOADS, PREC, to_dev
+from gdb_nerf_amd import synthetic
+from gdb_nerf_amd.engine import HotPathEngine
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+w = synthetic.make_nerf_weights(seed=0)
+bad = 0
+for wl_name in ("c2", "c4", "c5"):
+    wl = WORKLOADS[wl_name]
+    frame = to_dev(synthetic.make_frame(wl["Ho"], wl["Wo"], V=wl["V"], scene=wl["scene"], seed=0), "cuda")
+    for prec in ("f32", "f32x", "f16"):
+        eng = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"]); eng.load_weights(w); eng.precision = PREC[prec]
+        eng.prepare(frame)
+        ref = eng.render_packed().clone()
+        out = torch.empty_like(ref)
+        n = N if wl_name == "c2" else max(500, N // (10 if wl_name == "c4" else 60))
+        t0 = time.time(); mism = 0
+        for i in range(n):
+            if i % 250 == 0: eng.prepare(frame)           # the plan and pyramid are rebuilt now and then too
+            eng.render_packed(out=out)
+            if i % 500 == 499 and not torch.equal(out, ref): mism += 1
+        torch.cuda.synchronize()
+        mism += 0 if torch.equal(out, ref) else 1
+        bad += mism
+        print(f"{wl_name} {prec}: {n} launches in {time.time() - t0:.1f} s, {mism} mismatching checks", flush=True)
+print("soak:", "FAILED" if bad else "ok, every checked result bit-identical to the first")
+sys.exit(1 if bad else 0)
