@@ -382,6 +382,7 @@ struct FusedArgs {
     int row_begin, nrows, nseg, nsegs, ntiles, alias, skip;  // skip: timing-only ablation bits (diagnostic build)
     int ldo;          // floats per output row of bf: NOUT, or NOUT + 2 for the packed layout [feat | depth | opacity]
     int wave_floats;  // dense schedule: floats of LDS per wave (a workgroup may hold two waves, each with its own area)
+    int row_lo, row_hi, tile_stride;  // dense schedule: global rows (batch item x H + row) of this launch; tiles a wave skips per step
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     unsigned* dbg;    // diagnostic build only
 };
@@ -1680,48 +1681,53 @@ __device__ __forceinline__ float wave_shl1(float v) {
 __device__ __forceinline__ float wave_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
-// The grid of the dense schedule is sized for the worst case (every bundle at S_max: planMW windows per row) but its tiles are
-// numbered densely over the windows IN USE, so every workgroup up to the last live one carries work and the surplus ones all sit
-// at the end of the grid.  (Numbered row-major over the worst-case grid the surplus windows end every row, and dead workgroups
-// between live ones kept a quarter of the wave slots empty through the whole launch: 2.4 instead of 2.9 waves per SIMD in the
-// steady state of c2, profiles/r03/dense_occupancy.txt.)  A wave turns its tile index into (row, window) with one scan of the
-// per-row window counts plan_row left (WsLayout::nwinOff) - four rows per lane, 256 rows per round - restricted to the rows
-// [rlo, rhi) this launch renders.  Everything comes out wave-uniform.  Returns false when the wave has no tile.
-template <int NWG>
-__device__ __forceinline__ bool dense_tile(const DevFrame& f, int rlo, int rhi, int lane, int wv, int& rowid, int& win) {
+// Persistent tiles (round 4).  The launch is exactly the resident grid - as many workgroups as the chip holds at once (CUs x the
+// workgroups LDS and registers admit per CU, launch_dense_n) - and every wave WALKS tiles: XCD x owns the contiguous band
+// [x chunk, (x + 1) chunk) of the dense tile numbering, and the wave in slot s of that XCD renders tiles x chunk + s, + stride,
+// + 2 stride, ... (stride = the XCD's wave slots).  Static, so deterministic; no atomics, no cross-workgroup dependency; row
+// strips and batch items (grid y) stay bit-exact because a tile is still one window of one row.  Against one workgroup per tile
+// (round 3) no wave slot waits for the dispatcher between two tiles: the occupancy trace of that form showed the launch drop from
+// 3.0 to 2.05 resident waves per SIMD when the first round of workgroups ended together (profiles/r03/stamps_f32_schedule3.txt).
+// Tiles are numbered densely over the windows IN USE (plan_row leaves the count per row in WsLayout::nwinOff); a wave turns a
+// tile index into (row, window) with one scan of those counts - four rows per lane, 256 rows per round - restricted to the rows
+// [rlo, rhi) this launch renders.  Everything comes out wave-uniform.
+__device__ __forceinline__ int4 dense_counts(const DevFrame& f, int rlo, int rhi, int c0, int lane, int& s4) {
+    // this lane's four rows of round c0: clamped to what the plan was sized for, zero outside the strip
     const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;  // int4s of the count array that touch the strip
-    auto counts = [&](int c0, int& s4) {  // this lane's four rows of round c0: clamped to what the grid was sized for, zero outside the strip
-        const int q = c0 + lane;
-        int4 n = make_int4(0, 0, 0, 0);
-        if (q < nq) n = ((const int4*)f.nwin)[q0 + q];
-        const int r4 = (q0 + q) << 2;
-        n.x = (r4 + 0 >= rlo && r4 + 0 < rhi) ? min(max(n.x, 0), f.planMW) : 0;
-        n.y = (r4 + 1 >= rlo && r4 + 1 < rhi) ? min(max(n.y, 0), f.planMW) : 0;
-        n.z = (r4 + 2 >= rlo && r4 + 2 < rhi) ? min(max(n.z, 0), f.planMW) : 0;
-        n.w = (r4 + 3 >= rlo && r4 + 3 < rhi) ? min(max(n.w, 0), f.planMW) : 0;
-        s4 = n.x + n.y + n.z + n.w;
-        return n;
-    };
-    auto scan = [&](int v) {  // inclusive prefix over the 64 lanes
+    const int q = c0 + lane;
+    int4 n = make_int4(0, 0, 0, 0);
+    if (q < nq) n = ((const int4*)f.nwin)[q0 + q];
+    const int r4 = (q0 + q) << 2;
+    n.x = (r4 + 0 >= rlo && r4 + 0 < rhi) ? min(max(n.x, 0), f.planMW) : 0;
+    n.y = (r4 + 1 >= rlo && r4 + 1 < rhi) ? min(max(n.y, 0), f.planMW) : 0;
+    n.z = (r4 + 2 >= rlo && r4 + 2 < rhi) ? min(max(n.z, 0), f.planMW) : 0;
+    n.w = (r4 + 3 >= rlo && r4 + 3 < rhi) ? min(max(n.w, 0), f.planMW) : 0;
+    s4 = n.x + n.y + n.z + n.w;
+    return n;
+}
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {  // inclusive prefix over the 64 lanes
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d); if (lane >= d) v += u; }
-        return v;
-    };
-    int s4;
-    int4 n = counts(0, s4);
-    int incl = scan(s4);
-    int T = __shfl(incl, 63);
-    for (int c0 = 64; c0 < nq; c0 += 64) {  // strips of more than 256 rows: the total needs the later rounds too
-        int s; counts(c0, s);
-        T += __shfl(scan(s), 63);
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d); if (lane >= d) v += u; }
+    return v;
+}
+// live tiles of the rows [rlo, rhi)
+__device__ __forceinline__ int dense_total(const DevFrame& f, int rlo, int rhi, int lane) {
+    const int nq = ((rhi + 3) >> 2) - (rlo >> 2);
+    int T = 0;
+    for (int c0 = 0; c0 < nq; c0 += 64) {
+        int s; dense_counts(f, rlo, rhi, c0, lane, s);
+        T += __shfl(wave_scan_incl(s, lane), 63);
     }
-    // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2); each XCD gets one contiguous band of tiles
-    const int chunkd = ((T + NWG - 1) / NWG + 7) >> 3;
-    const int t = ((int)(blockIdx.x & 7) * chunkd + (int)(blockIdx.x >> 3)) * NWG + wv;
-    if ((int)(blockIdx.x >> 3) >= chunkd || t >= T) return false;
+    return T;
+}
+// tile t -> (row, window); false past the last tile
+__device__ __forceinline__ bool dense_lookup(const DevFrame& f, int rlo, int rhi, int lane, int t, int& rowid, int& win) {
+    const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;
     int run = 0;
     for (int c0 = 0; c0 < nq; c0 += 64) {
-        if (c0) { n = counts(c0, s4); incl = scan(s4); }
+        int s4;
+        const int4 n = dense_counts(f, rlo, rhi, c0, lane, s4);
+        const int incl = wave_scan_incl(s4, lane);
         const int tot = __shfl(incl, 63), tl = t - run;
         if (tl < tot) {
             const int ls = __builtin_ctzll(__ballot(tl < incl));  // the lane whose four rows hold the tile
@@ -1738,52 +1744,85 @@ __device__ __forceinline__ bool dense_tile(const DevFrame& f, int rlo, int rhi, 
 }
 
 template <int PREC, int WPS, int NWG>
-__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
+    // Everything wave-uniform is re-derived inside each tile iteration from an opaque pointer to the kernel-argument segment (as in
+    // k_render_solo): as loop invariants those values would be live across the whole body, which has no register to spare.
+    typedef const FusedArgs __attribute__((address_space(4))) KArgs;
+    KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    // ---- this wave's tiles: t0, t0 + stride, ... < tend ---------------------------------------------------------------------
+    // Rows are addressed by their global index (batch item x H + row), so one launch covers the rows [row_lo, row_hi) of ALL batch
+    // items and nothing but (t, tend) lives across a tile.
+    int t, tend;
+    {
+        const FusedArgs& a = *(const FusedArgs*)ap;
+        const int lane = threadIdx.x & 63, wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+        const int T = __builtin_amdgcn_readfirstlane(dense_total(a.f, a.row_lo, a.row_hi, lane));
+        const int chunk = (T + 7) >> 3;                 // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2)
+        const int xcd = (int)(blockIdx.x & 7);
+        t = xcd * chunk + (int)(blockIdx.x >> 3) * NWG + wv;
+        tend = min(T, (xcd + 1) * chunk);
+    }
+#ifdef GDB_DEBUG_STAMPS
+    int it = -1;
+#endif
+    while (t < tend) {
+    KArgs* apk = ap;
+    asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
+    const FusedArgs& a = *(const FusedArgs*)apk;
     const DevFrame& f = a.f;
-    const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int tcur = t;
+    t += a.tile_stride;            // (the XCD's wave slots: set by the launcher)
+    // ... and so is everything per-lane: nothing derived from the lane index may be hoisted out of the tile loop either
+    const int tid = opaque((int)threadIdx.x);
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    unsigned* dbg = a.dbg; (void)dbg;
+#ifdef GDB_DEBUG_STAMPS  // one stamp record per (wave slot, tile iteration)
+    ++it;
+    unsigned* dbg = a.dbg ? a.dbg + (size_t)it * gridDim.x * (16 * 16 * 2) : nullptr;
+#else
+    unsigned* dbg = nullptr; (void)dbg;
+#endif
     // ---- dense tile index -> (row, window) -------------------------------------------------------------------------------
-    const int bi = blockIdx.y;
     int rowid, win;
-    if (!dense_tile<NWG>(f, bi * f.H + a.row_begin, bi * f.H + a.row_begin + a.nrows, lane, wv, rowid, win)) return;
+    if (!dense_lookup(f, a.row_lo, a.row_hi, lane, tcur, rowid, win)) continue;
     rowid = __builtin_amdgcn_readfirstlane(rowid); win = __builtin_amdgcn_readfirstlane(win);
-    const int row = rowid - bi * f.H;
+    const int bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? rowid / f.H : 0), row = rowid - bi * f.H;
     typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
     const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
-    if (win >= krec[0]) return;  // (cannot happen with a plan that belongs to this depth prior)
+    if (win >= krec[0]) continue;  // (cannot happen with a plan that belongs to this depth prior)
     // This window = the row's sample offsets [s0, s0 + n), n <= 32, whole bundles (plan_row).  Everything read from the plan is
     // clamped to the frame, so that a plan that does not belong to this frame's depth prior renders garbage instead of reading or
     // writing outside the frame.
     const int s0 = min(max(krec[1 + win], 0), f.smapStride - 32);
     const int n = min(max(krec[2 + win] - s0, 0), 32);
-    if (n <= 0) return;
+    if (n <= 0) continue;
     const unsigned m = ldu<unsigned>(f.smap + (size_t)rowid * f.smapStride, 4u * (unsigned)(s0 + j));  // lane j = sample s0 + j of the row
     float tc[TAR_STRIDE];
     {
         const kfloat* tcg = kptr(tar_cam(f, bi));
+        asm volatile("" : "+s"(tcg));
 #pragma unroll
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
     STAMP(0);
-    const int mx = (int)(m & 0xFFFFu), k = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
+    const int mx = (int)(m & 0xFFFFu), k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
     // the window's bundles: first (lane 0's: a window starts at a bundle's first sample) .. the last lane's, nb <= 32
     const int first = min(max(__builtin_amdgcn_readfirstlane(mx), 0), f.W - 1);
     const int nb = min(max(__builtin_amdgcn_readlane(mx, n - 1) - first + 1, 0), min(32, f.W - first));
-    if (nb <= 0) return;
-    const int bj = min(max(mx - first, 0), nb - 1);          // this sample's bundle inside the window (= its output column)
-    const bool act = j < n && m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k >= 0 && k < mcnt && mcnt <= f.S_max;
+    if (nb <= 0) continue;
+    const int bj_g = min(max(mx - first, 0), nb - 1);        // this sample's bundle inside the window (= its output column)
+    const bool act = j < n && m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k_g >= 0 && k_g < mcnt && mcnt <= f.S_max;
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
-    float z; float vox[4];
-    int cnt;
+    float vox[4];
     {
+        float z_g;
         Bundle<4> q;
-        load_bundle<4, true, false>(f, tc, bi, row, first + bj, q);
-        q.count = cnt = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
+        load_bundle<4, true, false>(f, tc, bi, row, first + bj_g, q);
+        q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
-        slot_gather_q<PREC>(f, stage, tc, q, min(k, cnt - 1), bi, j, h, a.skip, act, z, vox);
+        slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
@@ -1800,17 +1839,31 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
         for (int i = 0; i < 4; ++i) v[16 + i] = fhv[i];
     }
     // ---- composite across the lanes of a bundle --------------------------------------------------------------------------
+    // The sample's slot, count and output column are decoded AGAIN from its list entry (one register across gather + MLP instead
+    // of four: the split-f16 build has none to spare).
+    const unsigned m_c = (unsigned)opaque((int)m);
+    const int k = (int)((m_c >> 16) & 0xFFu), cnt = min(max((int)(m_c >> 24), 1), f.S_max);
+    const int bj = min(max((int)(m_c & 0xFFFFu) - first, 0), nb - 1);
+    float z;  // the sample's depth, derived again from the depth prior (two loads the gather has left in L1 / L2) as bundle_sample does
+    {
+        const size_t hw = (size_t)f.H * f.W;
+        const unsigned pz = 4u * (unsigned)(row * f.W + first + bj);
+        float n0 = ldu<float>(f.depth_range + ((size_t)bi * 2) * hw, pz), f0 = ldu<float>(f.depth_range + ((size_t)bi * 2 + 1) * hw, pz);
+        if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
+        z = sample_mid<true>(n0, f0, cnt, min(k, cnt - 1));
+        if (f.inv_depth) z = gdiv<true>(1.f, z);
+    }
     const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
     const int S = f.S_max;
     if (S <= 4) {
         // An active sample's earlier samples are the lanes just below it in the same half (k <= j), a bundle's later samples the
         // lanes just above (they end at lane 31 at the latest): whole-wave DPP shifts never carry a value across a bundle's edge
         // that the predicates below do not mask.
-        float Tr = 1.f, ap = al;
+        float Tr = 1.f, ap_ = al;
 #pragma unroll
         for (int d = 1; d < 4; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
-            ap = wave_shr1(ap);
-            if (d <= k) Tr *= 1.f - ap;
+            ap_ = wave_shr1(ap_);
+            if (d <= k) Tr *= 1.f - ap_;
         }
         const float w = al * Tr;
 #pragma unroll
@@ -1818,22 +1871,23 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
         v[20] = w;
         v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
         // Segmented suffix sums as a Horner chain: acc <- v + (the bundle has a next sample ? acc of the next lane : 0); after
-        // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.
-        const float nxt = (act && k + 1 < cnt) ? 1.f : 0.f;
+        // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.  The neighbour is masked with a SELECT, not a
+        // multiply by 0: a non-finite sum of the next bundle must stay in its own bundle (as in the other schedules and the reference).
+        const bool has_next = act && k + 1 < cnt;
         float acc[22];
 #pragma unroll
         for (int i = 0; i < 22; ++i) acc[i] = v[i];
         for (int d = 1; d < S; ++d) {
 #pragma unroll
-            for (int i = 0; i < 22; ++i) acc[i] = fmaf(wave_shl1(acc[i]), nxt, v[i]);
+            for (int i = 0; i < 22; ++i) { const float nxv = wave_shl1(acc[i]); acc[i] = v[i] + (has_next ? nxv : 0.f); }
         }
 #pragma unroll
         for (int i = 0; i < 22; ++i) v[i] = acc[i];
     } else {
         float Tr = 1.f;
         for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
-            const float ap = __shfl_up(al, d, 32);
-            if (d <= k) Tr *= 1.f - ap;
+            const float ap_ = __shfl_up(al, d, 32);
+            if (d <= k) Tr *= 1.f - ap_;
         }
         const float w = al * Tr;
 #pragma unroll
@@ -1844,8 +1898,8 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
             const bool take = act && k + d < cnt;
 #pragma unroll
             for (int i = 0; i < 22; ++i) {
-                const float t = __shfl_down(v[i], d, 32);
-                if (take) v[i] += t;
+                const float tt = __shfl_down(v[i], d, 32);
+                if (take) v[i] += tt;
             }
         }
     }
@@ -1884,6 +1938,9 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a) {
         }
     }
     STAMP(8); STAMP(9);
+    __builtin_amdgcn_wave_barrier();  // the next tile's gather overwrites the area the stores above read
+    PHASE_FENCE();
+    }
 }
 
 // LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
@@ -1916,13 +1973,64 @@ static hipError_t launch_solo(const FusedArgs& a, unsigned grid, size_t lds, hip
 #ifndef GDB_DENSE_PREFER_WIDE
 #define GDB_DENSE_PREFER_WIDE 0
 #endif
+// Workgroups of this kernel a CU holds at once x the CUs of the device: the persistent grid.  Asked of the runtime once per
+// (kernel instantiation, device, LDS size) and kept in one atomic word per device ordinal (relaxed; two threads racing just ask twice).
+template <class K>
+static hipError_t resident_workgroups(K kernel, int threads, size_t lds, std::atomic<unsigned long long>* cache, int& per_cu, int& cus) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long key = (unsigned long long)lds & 0x3FFFFull;
+    if (dev < 64) {
+        const unsigned long long c = cache[dev].load(std::memory_order_relaxed);
+        if ((c >> 63) && (c & 0x3FFFFull) == key) { per_cu = (int)((c >> 18) & 0xFF); cus = (int)((c >> 26) & 0xFFF); return hipSuccess; }
+    }
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, threads, lds);
+    if (e != hipSuccess) return e;
+    // the LDS bound as the hardware allocates it (1280-byte granules): never above it, whatever the API says
+    const int by_lds = (int)((size_t)(160 * 1024) / ((lds + 1279) / 1280 * 1280));
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_lds ? (by_lds < 1 ? 1 : by_lds) : per_cu);
+    if (per_cu > 255) per_cu = 255;
+    if (cus < 1) cus = 1;
+    if (cus > 4095) cus = 4095;
+    if (dev < 64) cache[dev].store((1ull << 63) | ((unsigned long long)cus << 26) | ((unsigned long long)per_cu << 18) | key, std::memory_order_relaxed);
+    return hipSuccess;
+}
+
 template <int PREC, int WPS, int NWG>
 static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
+    static std::atomic<unsigned long long> resident[64];
     hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG>, done);
     if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(((a.ntiles + NWG - 1) / NWG + 7) / 8 * 8);  // a.ntiles: worst case per batch item; grid y = batch item
-    hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG>), dim3(grid, (unsigned)a.f.B), dim3(64 * NWG), NWG * lds, st, a);
+    int per_cu = 1, cus = 1;
+    e = resident_workgroups(k_render_dense<PREC, WPS, NWG>, 64 * NWG, NWG * lds, resident, per_cu, cus);
+    if (e != hipSuccess) return e;
+#ifdef GDB_DIAG  // diagnostic build: over- / under-subscribe the persistent grid (workgroups per CU) from the environment
+    static const int env_wgs = getenv("GDB_DENSE_WGS_PER_CU") ? atoi(getenv("GDB_DENSE_WGS_PER_CU")) : 0;
+    if (env_wgs > 0) per_cu = env_wgs;
+#endif
+    // The resident grid, shared between the batch items (grid y), never more workgroups than the worst case has tiles
+    // (a.ntiles: every bundle at S_max), a multiple of 8 (one octet = one workgroup per XCD).
+    long long grid = (long long)per_cu * cus;
+    grid = grid >= 8 ? grid / 8 * 8 : 8;
+    // One launch renders the rows [row_lo, row_hi) of the global row index (batch item x H + row): all batch items at once when
+    // the strip is the whole frame (or B = 1), one launch per batch item otherwise.
+    const bool whole = a.f.B == 1 || (a.row_begin == 0 && a.nrows == a.f.H);
+    const int nl = whole ? 1 : a.f.B;
+    for (int l = 0; l < nl; ++l) {
+        a.row_lo = (whole ? 0 : l * a.f.H) + a.row_begin;
+        a.row_hi = whole ? (a.f.B - 1) * a.f.H + a.row_begin + a.nrows : a.row_lo + a.nrows;
+        // never more workgroups than the worst case has tiles (every bundle at S_max)
+        const long long worst = (((long long)(a.row_hi - a.row_lo) * a.f.planMW + NWG - 1) / NWG + 7) / 8 * 8;
+        const long long g = grid > worst ? worst : grid;
+        a.tile_stride = (int)(g >> 3) * NWG;
+        hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 template <int PREC, int WPS>
@@ -2047,7 +2155,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
-    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0;
+    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     a.skip = env_skip; a.dbg = g_dbg;

@@ -305,13 +305,20 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, in
     load_bundle<BB, FAST>(f, tar_cam(f, bi), bi, h, w, q);
 }
 
+// Mid depth of sample k of a bundle (in disparity when inv_depth): the one value the dense schedule's composite derives a second
+// time from the depth prior instead of keeping it in a register across gather + MLP.  bundle_sampler.py:183, :246
+template <bool FAST>
+__device__ __forceinline__ float sample_mid(float nearv, float farv, int count, int k) {
+    float step = gdiv<FAST>(farv - nearv, (float)count);
+    float t0 = nearv + step * (float)k, t1 = nearv + step * (float)(k + 1);
+    return 0.5f * (t0 + t1);
+}
+
 // One sample of a bundle: mid depth, normalised volume depth, sub-ray points, sphere radius.
 template <int BB, bool FAST = false>
 __device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB>& q, int k, float& z, float& dnorm,
                                               float xyz[BB][3], float ctr[3], float& ball) {
-    float step = gdiv<FAST>(q.farv - q.nearv, (float)q.count);
-    float t0 = q.nearv + step * (float)k, t1 = q.nearv + step * (float)(k + 1);  // :183
-    z = 0.5f * (t0 + t1);                                                        // :246
+    z = sample_mid<FAST>(q.nearv, q.farv, q.count, k);                           // :183, :246
     dnorm = gdiv<FAST>(2.f * (z - q.vnear), q.vfar - q.vnear) - 1.f;             // :247
     if (f.inv_depth) z = gdiv<FAST>(1.f, z);                                     // :250-251
     float s[3] = {0.f, 0.f, 0.f};

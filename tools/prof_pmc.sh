@@ -16,6 +16,7 @@ GROUPS_=(
  "WRITE_SIZE TCC_HIT TCC_MISS"
  "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES"
  "TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS GRBM_GUI_ACTIVE GRBM_TA_BUSY"
+ "SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_LEVEL_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32"
 )
 i=0
 for g in "${GROUPS_[@]}"; do
