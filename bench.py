@@ -74,6 +74,19 @@ def alg_flops(n_samples, V):
     return float(n_samples) * (V * 18200 + 5248)
 
 
+def kernel_source_sha16():
+    """sha256 (16 hex digits) of the sources the fused kernels' code and memory traffic come from — gdb_fused.hip, gdb_internal.h
+    (load_bundle, ws_layout, the sample-list stride) and gdb_ops.hip (the plan) — comments and blank lines removed.
+    tools/profile_round.sh stamps profiles/traffic.json with the same function."""
+    import hashlib
+    import re
+    code = []
+    for name in ("gdb_fused.hip", "gdb_internal.h", "gdb_ops.hip"):
+        src = open(os.path.join(ROOT, "gdb-nerf_amd", "csrc", name), encoding="utf-8").read()
+        code.append("\n".join(l.rstrip() for l in re.sub(r"//[^\n]*", "", src).splitlines() if l.strip()))
+    return hashlib.sha256("\n".join(code).encode()).hexdigest()[:16]
+
+
 def to_dev(frame, dev):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in frame.items()}
 
@@ -126,11 +139,12 @@ def measure_peaks(dev):
                    "2048 workgroups x 4 waves x 4 accumulators (best of 3)"}
 
 
-def cpu_baseline(wl, frame, weights):
+def cpu_baseline(wl, frame, weights, quick=False):
     """the pure-PyTorch CPU restatement of the hot path (oracle/gdb_oracle_torch.py: the torch CPU kernels the
     reference itself would run, pinned to the numpy oracle and through it to the reference's fixtures) on this host's cores —
-    `torch.set_num_threads(os.cpu_count())` and an 8-thread row, 3 frames each, first dropped, mean of the rest.  The numpy oracle
-    (single-threaded element-wise numpy, the parity checker) is timed beside it for reference."""
+    rows at 8 / 32 / 64 threads (3 frames each after one dropped; `value` = the fastest row, `cores` = its thread count) and the
+    os.cpu_count() row on c1 only.  The numpy oracle (single-threaded element-wise numpy, the parity checker) is timed beside it.
+    quick: the 8-thread row only (rank 0 of an N > 1 run)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gdb_oracle  # the checker, used here only as the reported CPU baseline
     import gdb_oracle_torch
@@ -156,30 +170,38 @@ def cpu_baseline(wl, frame, weights):
         return float(np.mean(t[1:]))
     before = torch.get_num_threads()
     rows = []
-    for threads in (8, ncpu):
+    # thread counts: 8, 32, 64 (what fits the host); the all-hardware-threads row is taken on c1 only — on a 256-thread host these
+    # small torch CPU kernels oversubscribe and ONE c2 frame at os.cpu_count() threads took 38 s (round 3), which says nothing
+    # about the host and cost the default run most of its time
+    counts = [8] if quick else sorted({t for t in (8, 32, 64) if t <= max(8, ncpu)})
+    for threads in counts:
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
         gdb_oracle_torch.hot_path(frame, weights, **kw)          # first frame, dropped when more follow
         first = time.perf_counter() - t0
         if first <= 8.0:
             s_, note = timed(lambda: gdb_oracle_torch.hot_path(frame, weights, **kw), reps=3), "mean of 2 frames after 2 dropped"
-        else:  # (the torch CPU kernels of this path oversubscribe badly on a 256-thread host: keep the default run within minutes)
+        else:
             s_, note = first, "ONE frame (it took more than 8 s: not repeated)"
         rows.append({"impl": "torch", "threads": threads, "value": Ho * Wo / s_, "s_per_frame": s_, "frames": note})
     best = max(rows, key=lambda r: r["value"])
     # c1 (64x80, the reference's own CPU-runnable case) is always reported beside the benched workload
     c1 = WORKLOADS["c1"]
     f1 = synthetic.make_frame(c1["Ho"], c1["Wo"], V=c1["V"], scene=c1["scene"], seed=0)
-    torch.set_num_threads(8)
-    s1 = timed(lambda: gdb_oracle_torch.hot_path(f1, weights, max_num_samples=c1["S"], is_adaptive=c1["adaptive"]))
-    c1_row = {"workload": "c1 64x80", "impl": "torch", "threads": 8, "value": c1["Ho"] * c1["Wo"] / s1, "s_per_frame": s1}
+    c1_rows = []
+    for threads in ([8] if quick else sorted({8, ncpu})):
+        torch.set_num_threads(threads)
+        s1 = timed(lambda: gdb_oracle_torch.hot_path(f1, weights, max_num_samples=c1["S"], is_adaptive=c1["adaptive"]))
+        c1_rows.append({"workload": "c1 64x80", "impl": "torch", "threads": threads, "value": c1["Ho"] * c1["Wo"] / s1, "s_per_frame": s1})
     torch.set_num_threads(before)
-    sn = timed(lambda: gdb_oracle.hot_path(frame, weights, **kw), reps=2)
-    rows.append({"impl": "numpy oracle (the parity checker)", "threads": 1, "value": Ho * Wo / sn, "s_per_frame": sn})
+    if not quick:
+        sn = timed(lambda: gdb_oracle.hot_path(frame, weights, **kw), reps=2)
+        rows.append({"impl": "numpy oracle (the parity checker)", "threads": 1, "value": Ho * Wo / sn, "s_per_frame": sn})
     return {"value": best["value"], "unit": "rays/s", "cores": best["threads"], "kind": "port", "cpu_model": model, "host_cores": ncpu,
-            "rows": rows, "c1": c1_row,
-            "sample": f"full frames of {Ho}x{Wo} through the pure-PyTorch fp32 restatement of the hot path, torch.set_num_threads(8) and "
-                      f"({ncpu}) (per row: see `frames`); value = the faster row; numpy oracle: 2 frames, first dropped"}
+            "rows": rows, "c1": c1_rows[0], "c1_rows": c1_rows,
+            "sample": f"full frames of {Ho}x{Wo} through the pure-PyTorch fp32 restatement of the hot path at torch.set_num_threads("
+                      f"{', '.join(str(c) for c in counts)}) (per row: see `frames`); value = the fastest row, cores = its thread count; "
+                      f"the os.cpu_count() = {ncpu} row on c1 only (c1_rows); numpy oracle: 2 frames, first dropped"}
 
 
 def frame_time_ms(dev, precision="f32"):
@@ -207,13 +229,14 @@ class Timed:
     kernel's duration is sampled in a pass of its own (`sample`: every step carries an event pair around the kernel / the
     collective), so that `kernel_ms` is a mean over >= 20 launches whatever K is."""
 
-    def __init__(self, dist, dev, rehearse):
-        self.dist, self.dev, self.rehearse = dist, dev, rehearse
+    def __init__(self, dist, dev, rehearse, cuda=True):
+        self.dist, self.dev, self.rehearse, self.cuda = dist, dev, rehearse, cuda
 
     def sync(self):
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
 
     def rewarm(self, fn, ms):
         """Untimed steps for `ms` of wall time: the clocks this workload holds have settled before anything is measured."""
@@ -245,6 +268,60 @@ class Timed:
         self.sync()
 
 
+def self_launch(n):
+    """Run this very command line under torch.distributed.run with n ranks on this node (one per GPU) as a child process; relay
+    what the ranks print on stdout (rank 0's one JSON line) and the launcher's exit code.  The reference's only process-group
+    bootstrap is the DDP launch of train_net.py:106-111 (`torch.distributed.launch`); the driver's N > 1 form is the same thing."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout.splitlines():   # stdout carries rank 0's line and nothing else (gloo / RCCL chatter of the ranks goes to stderr)
+        print(line, file=sys.stdout if line.startswith('{"metric"') else sys.stderr, flush=True)
+    if p.returncode != 0:
+        raise SystemExit(p.returncode)
+
+
+def plumbing_only(args, world, rank):
+    """GDB_BENCH_REHEARSE=1 on a host without any GPU: everything of the N > 1 run except the HIP calls — gloo rendezvous from the
+    launcher's environment, the barrier + max-over-ranks timing protocol, the strip all-gather (StripGather on CPU tensors, a
+    stand-in renderer that writes exactly the rows it is asked for), the per-rank gather of the report fields, rank 0's one line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    try:
+        wl = WORKLOADS["c1"]
+        H, W, C = wl["Ho"] // 2, wl["Wo"] // 2, 41
+        truth = torch.arange(H * W * C, dtype=torch.float32).view(H, W * C)
+        gather = StripGather(H, W, C, world, rank, "cpu", dist)
+        r0, r1 = gather.strip
+        timed = Timed(dist, torch.device("cpu"), True, cuda=False)
+
+        def step(sample):
+            gather.full.view(H, W * C)[r0:r1] = truth[r0:r1]
+            gather.gather()
+        dt = timed.run(step, args.warmup, args.steps)
+        ok = bool(torch.equal(gather.full.view(H, W * C), truth))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "strip": [r0, r1], "kernel_ms": None})
+        if rank == 0:
+            print(json.dumps({"metric": "rendered rays/sec, GDB-NeRF hot path (sample+fetch+MLP+composite)", "value": None, "unit": "rays/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "none",
+                              "plumbing_only": True, "world_size": world, "gathered_equals_full_render": ok, "per_rank": per_rank,
+                              "note": "no GPU on this host: launch, rendezvous, timing protocol, strip all-gather and report "
+                                      "plumbing rehearsed over gloo with a stand-in renderer; not a measurement"}), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
 def ev_ms(pairs):
     return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else None
 
@@ -273,16 +350,26 @@ def main():
                          "workspaces, so one frame's fill/drain overlaps the next; per-launch durations then overlap too (default 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver's N = 1 command form has it: start the N ranks ourselves.  This process has
+        # not touched the GPU (no torch.cuda call above) and never will: the ranks are fresh children of torch.distributed.run,
+        # rank 0's JSON line and the launcher's exit code are relayed.
+        return self_launch(args.gpus)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
     # GDB_BENCH_REHEARSE=1: several ranks share the visible GPU(s) over gloo (collective staged through host memory) — a
     # logic rehearsal of the N > 1 path on a one-GPU box, never a measurement.
     rehearse = os.environ.get("GDB_BENCH_REHEARSE") == "1"
+    if rehearse and world > 1 and not torch.cuda.is_available():
+        # no GPU at all (the authoring container, the CPU test suite): rehearse the launch / rendezvous / timing / gather / report
+        # plumbing alone, with a stand-in for the render.  Says so in the line; carries no measurement.
+        return plumbing_only(args, world, rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
     local = local % torch.cuda.device_count() if rehearse else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -346,7 +433,7 @@ def main():
     def events():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def step_frame(sample, precision=None, pairs=kern_pairs):
+    def step_frame(sample, precision=None, pairs=kern_pairs, eng=eng, out=out):
         """prepare + hot path on this rank's whole frame."""
         if args.streams > 1:  # frame i on stream i % n: prepare + render back to back on that stream
             e, o, st = lanes[counter[0] % len(lanes)]
@@ -461,17 +548,13 @@ def main():
         # PMC numbers can only be collected under rocprofv3 (tools/profile_round.sh), so they are static between profile runs: the
         # file records the sha256 of the kernel source it was measured on, and a number measured on another source is refused
         try:
-            import hashlib
             tj = json.load(open(tpath))
-            import re
-            src = open(os.path.join(ROOT, "gdb-nerf_amd", "csrc", "gdb_fused.hip"), encoding="utf-8").read()
-            code = "\n".join(l.rstrip() for l in re.sub(r"//[^\n]*", "", src).splitlines() if l.strip())   # (comments and blank lines do not change a kernel)
-            src_sha = hashlib.sha256(code.encode()).hexdigest()[:16]
+            src_sha = kernel_source_sha16()
             if tj.get("_kernel_source_sha256_16") == src_sha:
                 traffic = tj.get(f"{args.workload}:{kname}:{pname}")
                 tsrc = tj.get("_source")
             else:
-                tsrc = f"profiles/traffic.json was measured on another gdb_fused.hip ({tj.get('_kernel_source_sha256_16')} != {src_sha}): refused"
+                tsrc = f"profiles/traffic.json was measured on other kernel sources ({tj.get('_kernel_source_sha256_16')} != {src_sha}): refused"
         except Exception:
             traffic = None
     # Which roofline bounds the kernel: the larger of the two floors.  At fp32 the MLP's algorithmic flops
@@ -494,7 +577,10 @@ def main():
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
                    "path": args.path, "precision": pname, "schedule": args.schedule, "shard": args.shard if world > 1 else "none",
                    "prewarm_ms": args.prewarm_ms, "streams": args.streams,
-                   "frame_ring": nring, "input_MB_per_frame": round(in_bytes / 1e6, 1)},
+                   "frame_ring": nring, "input_MB_per_frame": round(in_bytes / 1e6, 1),
+                   "timed_region": f"{args.steps} steps over a ring of {nring} distinct HBM copies of the frame "
+                                   f"({nring * in_bytes / 1e6:.0f} MB > the 256 MiB Infinity Cache): each copy is read {args.steps / nring:.1f} times, "
+                                   f"never twice in a row"},
         "t_hot_ms": ms_per_step, "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
         "roofline": roof,
     }
@@ -529,6 +615,32 @@ def main():
         if "f32x" in others[1:]:
             res["secondary_f32x"] = time_other("f32x")
         del ubf
+        # north_star's "x 8 samples": S_max 8 on the c2 shape, adaptive (dense schedule) and fixed (segment wave), each with its own
+        # engine, re-warm, a region of >= 300 steps and its own ACTUAL sample count (configs/dtu_eval.yaml:7 has S_max 3,
+        # dtu_pretrain.yaml:35 has 6; the reference has no 8: SURVEY.md 8(a) note)
+        def time_smax(smax, adaptive):
+            e8 = HotPathEngine(max_num_samples=smax, is_adaptive=adaptive, device=dev)
+            e8.set_schedule(args.schedule); e8.precision = prec; e8.load_weights(weights_np); e8.prepare(frame)
+            o8 = tuple(torch.zeros_like(t) for t in out)
+            pairs8 = []
+            fn8 = lambda smp: step_frame(smp, prec, pairs8, e8, o8)
+            timed.rewarm(fn8, 100.0)
+            dt8 = timed.run(fn8, 50, k2)
+            timed.sample(fn8)
+            km8 = ev_ms(pairs8)
+            ns8 = int(e8.sample()["total"].item())
+            af8 = alg_flops(ns8, V)
+            sched8 = args.schedule or (3 if adaptive else (1 if smax <= 3 else 2))
+            return {"S_max": smax, "sampling": "adaptive" if adaptive else "fixed", "precision": args.precision,
+                    "kernel": {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense"}[sched8],
+                    "value": Ho * Wo * k2 / dt8, "ms_per_step": dt8 / k2 * 1e3, "steps": k2, "kernel_ms": km8, "n_samples": ns8,
+                    "hbm_frac": ab / (km8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "mfma_frac": af8 / (km8 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[pname]}
+        if args.workload == "c2" and not args.smax:
+            try:
+                res["smax8_adaptive"] = time_smax(8, True)
+                res["smax8_fixed"] = time_smax(8, False)
+            except Exception as ex:  # measurement extras never take the headline down
+                res["smax8_error"] = repr(ex)
         # throughput of a sweep over independent frames with two frames in flight: frame i on HIP stream i % 2 (own engine,
         # workspace and outputs), so one frame's fill / drain overlaps its neighbour's steady state.  Reported beside the headline,
         # never as it: per-launch durations overlap in this mode.
@@ -561,12 +673,18 @@ def main():
         except Exception as ex:
             res["t_frame_ms"] = None
             res["t_frame_error"] = repr(ex)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(wl, frame_np, weights_np)
+    if dist is not None:
+        # every rank's dominant-kernel time and roofline fraction ride in rank 0's line (the line's `roofline` is rank 0's own)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "rows": [r0, r1], "kernel_ms": kern_ms, "roofline_frac": roof["frac"],
+                                          "bound": roof["bound"], "hbm_frac": hbm_frac, "mfma_frac": mfma_frac})
+        res["per_rank"] = per_rank
+        dist.destroy_process_group()
+    if rank == 0 and not args.no_cpu_baseline:
+        # N > 1: the 8-thread row only, on rank 0, after the process group is gone (no rank waits on it)
+        res["cpu_baseline"] = cpu_baseline(wl, frame_np, weights_np, quick=world > 1)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

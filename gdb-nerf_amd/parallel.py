@@ -41,13 +41,15 @@ class StripGather:
     itself (the all-gather's own in-place form: send == recv + rank * count).  Otherwise the strip goes through
     one padded (world, rows, W*C) buffer.  `nbytes` is what one rank receives per call (the bus-bandwidth numerator)."""
 
-    def __init__(self, H: int, W: int, C: int, world: int, rank: int, device, dist, dtype=torch.float32, stage_cpu: bool = False):
+    def __init__(self, H: int, W: int, C: int, world: int, rank: int, device, dist, dtype=torch.float32, stage_cpu: bool = False,
+                 force_padded: bool = False):
         self.H, self.W, self.C, self.world, self.rank, self.dist = H, W, C, world, rank, dist
         # stage_cpu: the collective runs on host copies (gloo cannot move device tensors: the one-GPU rehearsal of bench.py)
         self.stage_cpu = stage_cpu and torch.device(device).type != "cpu"
         self.strip = row_strip(H, rank, world)
         self.full = torch.zeros((H * W, C), dtype=dtype, device=device)
-        self.even = world == 1 or H % world == 0
+        # force_padded: take the padded form although the rows divide evenly (tests: both collective forms on one rank count)
+        self.even = (world == 1 or H % world == 0) and not force_padded
         self.rows = -(-H // world)
         self._rowview = self.full.view(H, W * C)
         if not self.even:
@@ -55,8 +57,10 @@ class StripGather:
             self._send = torch.zeros((self.rows, W * C), dtype=dtype, device=device)  # pad rows zeroed once, never re-written
         self.nbytes = (world - 1) * self.rows * W * C * self.full.element_size()
 
-    def gather(self) -> torch.Tensor:
-        if self.world == 1:
+    def gather(self, always_collective: bool = False) -> torch.Tensor:
+        """always_collective: run the collective at world size 1 as well (a one-rank RCCL communicator then sees exactly the call
+        an N-rank job makes, in-place aliasing included: tests/test_parallel.py::test_strip_gather_through_one_rank_rccl)."""
+        if self.world == 1 and not always_collective:
             return self.full
         r0, r1 = self.strip
         if self.stage_cpu:

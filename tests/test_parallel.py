@@ -164,3 +164,116 @@ def test_network_forward_shards_rows_over_ranks(world, B, H, W):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+def test_strip_gather_collective_at_world_1_gloo():
+    """`gather(always_collective=True)` takes the real all_gather_into_tensor branch on a ONE-rank group too - in place (the send
+    view aliases the receive buffer: send == recv + rank * count) and through the padded buffer - and leaves the rows as they were."""
+    from gdb_nerf_amd.parallel import StripGather
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        H, W, C = 6, 5, 41
+        truth = torch.arange(H * W * C, dtype=torch.float32).view(H * W, C)
+        for padded in (False, True):
+            g = StripGather(H, W, C, 1, 0, "cpu", dist, force_padded=padded)
+            assert g.even == (not padded) and g.strip == (0, H)
+            g.full.copy_(truth)
+            out = g.gather(always_collective=True)
+            assert out is g.full and torch.equal(out, truth)
+            if padded:
+                assert torch.equal(g._recv[0].reshape(H * W, C), truth)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_strip_gather_through_one_rank_rccl():
+    """The first thing a multi-GPU run does that no one-GPU run did in three rounds: hand RCCL the all-gather of a packed render.
+    A ONE-rank "nccl" communicator (RCCL on ROCm) on the box's GPU takes StripGather through the real all_gather_into_tensor call,
+    in place (send view aliasing the receive buffer) and padded, on an actual render_packed result: bit-identical rows afterwards.
+    Reference: the only process-group bootstrap the reference has is train_net.py:106-111 (DDP init); the all-gather of rendered
+    strips is north_star's."""
+    from gdb_nerf_amd import synthetic
+    from gdb_nerf_amd.engine import HotPathEngine
+    from gdb_nerf_amd.parallel import StripGather
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        fr = synthetic.make_frame(64, 80, V=3, seed=0)
+        eng = HotPathEngine(max_num_samples=3, is_adaptive=True, device=dev)
+        eng.load_weights(synthetic.make_nerf_weights(seed=0))
+        eng.prepare({k: torch.from_numpy(v).to(dev) for k, v in fr.items()})
+        H, W, C = 32, 40, eng.Q + 2
+        want = eng.render_packed(0, H).clone()
+        for padded in (False, True):
+            g = StripGather(H, W, C, 1, 0, dev, dist, force_padded=padded)
+            for rep in range(2):   # buffers reused call after call
+                g.full.fill_(float("nan"))
+                eng.render_packed(*g.strip, None, g.full)
+                out = g.gather(always_collective=True)
+                torch.cuda.synchronize()
+                assert out is g.full and torch.equal(out, want), (padded, rep)
+                if padded:
+                    assert torch.equal(g._recv[0].reshape(H * W, C), want)
+        # the collective the bench times on N ranks, once: a barrier and a MAX all-reduce of the step time on the device
+        dist.barrier()
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.25
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment - the command form the driver uses - starts its own two ranks
+    under torch.distributed.run and relays rank 0's ONE JSON line and the exit code (as written it exited at the
+    WORLD_SIZE check).  This host has no GPU, so under GDB_BENCH_REHEARSE=1 the ranks rehearse the plumbing alone (gloo rendezvous
+    from the launcher's environment, barrier + max-over-ranks timing, the strip all-gather, the per-rank report) and say so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GDB_BENCH_REHEARSE="1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["plumbing_only"] is True and rec["gathered_equals_full_render"] is True
+    assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1]
+    # a failing rank is not swallowed: the launcher's exit code comes back
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env={k: v for k, v in env.items() if k != "GDB_BENCH_REHEARSE"}, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "needs a GPU" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_self_launched_on_one_gpu():
+    """The same command form on the GPU box: `python bench.py --gpus 2` starts two ranks that share the one card (GDB_BENCH_REHEARSE=1:
+    gloo, the all-gather staged through host memory - a rehearsal of the product path, never a measurement).  The line must carry
+    what an N > 1 record is graded on: both modes, the gathered strips equal to the full render, every rank's kernel time and
+    roofline fraction, and rank 0's CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GDB_BENCH_REHEARSE="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["gathered_equals_full_render"] is True and "independent_frames" in rec
+    assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1]
+    assert all(r["kernel_ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in rec["per_rank"])
+    assert rec["per_rank"][0]["rows"] == [0, 128] and rec["per_rank"][1]["rows"] == [128, 256]
+    assert rec["cpu_baseline"]["cores"] == 8 and rec["cpu_baseline"]["value"] > 0

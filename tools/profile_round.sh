@@ -37,14 +37,13 @@ for p in ("f32", "f32x", "f16"):
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print("fused kernel HBM traffic per launch (bytes):", res["traffic_bytes"])
 # traffic.json for bench.py's roofline.traffic, stamped with the kernel source it was measured on (bench.py refuses it otherwise)
-import hashlib
-root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
-import re
-src = open(os.path.join("$ROOT", "gdb-nerf_amd", "csrc", "gdb_fused.hip"), encoding="utf-8").read()
-code = "\n".join(l.rstrip() for l in re.sub(r"//[^\n]*", "", src).splitlines() if l.strip())   # comments and blank lines do not change a kernel
-sha = hashlib.sha256(code.encode()).hexdigest()[:16]
+import sys
+sys.path.insert(0, "$ROOT")
+from bench import kernel_source_sha16   # gdb_fused.hip + gdb_internal.h + gdb_ops.hip, comments stripped: what bench.py checks
+sha = kernel_source_sha16()
 tj = dict(res["traffic_bytes"])
 tj["_kernel_source_sha256_16"] = sha
 tj["_source"] = "profiles/$TAG/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, per launch: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; MI355X guide, HBM section)"
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print("traffic.json written to", out, "- copy it to profiles/traffic.json (the file bench.py reads) together with the summaries")
 PY
