@@ -214,7 +214,7 @@ def frame_time_ms(dev, precision="f32"):
     batch = {"src_views": {"rgb": t(fr["src_images"]), "extrinsics": t(fr["src_exts"]), "intrinsics": t(fr["src_ints"])},
              "tar_views": {"extrinsics": t(fr["tar_ext"]), "intrinsics": t(fr["tar_int"])}, "near_far": t(fr["near_far"])}
     torch.manual_seed(0)
-    net = make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.precision", precision])).eval().to(dev)
+    net = make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.precision", precision, "nerf.reuse_outputs", "True"])).eval().to(dev)
     times = []
     with torch.no_grad():
         for _ in range(14):

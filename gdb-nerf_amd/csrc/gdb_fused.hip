@@ -923,7 +923,10 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
         const Frag<X> gm0 = load_fragx<X>(mf, F_GMEAN, lane_o), gm1 = load_fragx<X>(mf, F_GMEAN + 1, lane_o);
         a_ga0 = load_fragx<X>(mf, F_GA, lane_o); a_ga1 = load_fragx<X>(mf, F_GA + 1, lane_o);  // next phase
         w_agg = load_tab(mf, TD_AGG, h_o);
-        // sum and sum of squares (var = (sum g^2 - V mean^2) / (V - 1)): two instructions per value and view, Welford's update four
+        // sum and sum of squares (var = (sum g^2 - V mean^2) / (V - 1)): two instructions per value and view, Welford's update four.
+        // Cancellation: 1e-7 |g|^2 absolute on the variance - below what the operand rounding of these two paths does to it for
+        // O(1) features (f16 operands: 5e-4 relative; operand pairs: 2.4e-7 relative); the exact-fp32 core (slot_mlp_core_f32)
+        // accumulates around a shift instead, which needs twelve registers this core does not have at three waves per SIMD.
         f32x16 mean, m2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { mean[i] = 0.f; m2[i] = 0.f; }
@@ -1210,23 +1213,29 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         load_quads<8>(m32, Q_GMEAN, lane_o, wm);
         base = load_tab(m32, T32_GLOB, h_o);
         load_quads<12>(m32, Q_GA, lane_o, wg);  // next phase
-        // sum and sum of squares: var = (sum g^2 - V mean^2) / (V - 1).  (Welford's update costs four instructions per value
-        // and view against two; with g = O(1) the cancellation stays at the 1e-7 level of the operands.)
-        float s1[12], s2[12];
+        // Sums of d = g_v - g_0 and of d^2 (shifted data: mean = g_0 + sum d / V, var = (sum d^2 - (sum d)^2 / V) / (V - 1)).  Two
+        // instructions per value and view like the plain sum / sum of squares (view 0 is the shift and adds nothing; the others pay
+        // one subtraction), Welford's update four - but the cancellation is relative to the SPREAD of g over the views, not to its
+        // magnitude (unnormalised FPN features of a real checkpoint; torch.var_mean is two-pass), and equal views give exactly 0.
+        float g0[12], s1[12], s2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        {
+            const Tail32 tl = load_tail32<true>(stage, j, h);
+            view_g32(tl, q_view, b_view, g0);
+        }
 #pragma unroll 1
-        for (int v = 0; v < V; ++v) {
+        for (int v = 1; v < V; ++v) {
             const Tail32 tl = load_tail32<true>(stage + (size_t)v * STAGE_V, j, h);
             float g[12];
             view_g32(tl, q_view, b_view, g);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { s1[i] += g[i]; s2[i] = fmaf(g[i], g[i], s2[i]); }
+            for (int i = 0; i < 12; ++i) { const float d = g[i] - g0[i]; s1[i] += d; s2[i] = fmaf(d, d, s2[i]); }
         }
         const float rv = frcp((float)V), iv = frcp((float)(V - 1));
         float mean[12], m2[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) { mean[i] = s1[i] * rv; m2[i] = (s2[i] - s1[i] * mean[i]) * iv; }
+        for (int i = 0; i < 12; ++i) { const float md = s1[i] * rv; mean[i] = g0[i] + md; m2[i] = (s2[i] - s1[i] * md) * iv; }
         // mean channels 16..18 (half 0 of registers 8..10) move into half 1 of the variance registers 8..10, whose own
         // channels (20..22) do not exist: the mean chain then needs 8 steps instead of 12
         swap32_3(m2[8], mean[8], m2[9], mean[9], m2[10], mean[10]);

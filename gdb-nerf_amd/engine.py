@@ -65,10 +65,13 @@ def _chk(t: torch.Tensor, name: str, shape=None, dtype=torch.float32) -> torch.T
 class HotPathEngine:
     """One engine per (config, device).  Not thread-safe: one frame in flight per engine.
 
-    Output buffers: by default every call returns fresh tensors.  With `reuse_outputs = True` (what `Network.forward` sets:
-    `nerf.reuse_outputs`, default on) the tensors `render`, `render_packed`, `decode` and `merge` return when no `out` is passed
-    are per-engine buffers, allocated once per shape and OVERWRITTEN by the next call of the same method — no allocation and no
-    memset in the per-frame path (every element is written by the kernels).  Clone what must outlive the next frame."""
+    Output buffers: by default every call returns fresh tensors.  With `reuse_outputs = True` the tensors `render`,
+    `render_packed`, `decode` and `merge` return when no `out` is passed are per-engine buffers, allocated once per shape and
+    OVERWRITTEN by the next call of the same method — no allocation and no memset in the per-frame path (every element is written
+    by the kernels); clone what must outlive the next frame.  `reuse_internal = True` (what `Network.forward` sets) does that
+    for the intermediates of a frame only — the packed render and the decoder's image, which a caller of the network never sees —
+    while `merge` / `merge_packed` still return fresh tensors, as the reference's forward does (`nerf.reuse_outputs: true` turns
+    the full reuse on, for loops that consume a frame's outputs before the next forward: bench.py, tools/bench_network.py)."""
 
     def __init__(self, *, bundle_size: int = 2, max_num_samples: int = 3, is_adaptive: bool = True,
                  inv_depth: bool = False, global_num_depth: int = 64, max_mipmap_level: int = 3,
@@ -90,14 +93,16 @@ class HotPathEngine:
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
         self.reuse_outputs = False
+        self.reuse_internal = False
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self.mip_levels: Optional[int] = None  # levels built beyond level 0 by the last prepare()
         self._warned_levels = False
 
-    def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
-        """Per-engine output buffer (see the class docstring); a fresh uninitialised tensor when reuse is off."""
+    def _buf(self, name: str, shape, dtype=torch.float32, internal: bool = False) -> torch.Tensor:
+        """Per-engine output buffer (see the class docstring); a fresh uninitialised tensor when reuse is off.
+        internal: an intermediate of a frame (packed render, decoder image) - also reused under `reuse_internal`."""
         shape = tuple(int(x) for x in shape)
-        if not self.reuse_outputs:
+        if not (self.reuse_outputs or (internal and self.reuse_internal)):
             return torch.empty(shape, dtype=dtype, device=self.device)  # (no zero-fill either: the kernels write every element)
         key = (name, shape, dtype)
         t = self._bufs.get(key)
@@ -192,8 +197,7 @@ class HotPathEngine:
         self._frame, self._keep = f, dict(frame)
         # gdb_prepare builds the dense schedule's plan from the depth prior as it is NOW (adaptive configs); a later render may
         # skip its own rebuild (GDB_SCHED_PLAN_READY) only while that tensor is unchanged: same storage, same version counter
-        dr = frame.get("depth_range")
-        self._plan_key = (dr.data_ptr(), dr._version) if (dr is not None and self.cfg.is_adaptive) else None
+        self._plan_key = None   # armed only once gdb_prepare has returned OK (below)
         if "src_images" in frame:
             lay = (C.c_size_t * 7)()
             _lib.check(self.lib.gdb_pyramid_layout(C.byref(self.cfg), C.byref(f), lay))
@@ -208,7 +212,29 @@ class HotPathEngine:
             _lib.check(self.lib.gdb_prepare_fpn(C.byref(self.cfg), C.byref(f), fpn.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._stream()))
         else:
             _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        if self.cfg.is_adaptive:
+            self._plan_key = self._prior_key(frame.get("depth_range"))
         return self.mip_levels
+
+    @staticmethod
+    def _prior_key(dr: Optional[torch.Tensor]):
+        """(storage pointer, version counter) of the depth prior, or None when the tensor has no version counter to watch (tensors
+        created under torch.inference_mode(): `_version` raises) - the render then rebuilds the plan itself on every call (k_plan,
+        a ~1 us launch).  Writes that bypass the counter (`.data.copy_`, an external kernel writing through data_ptr) are not seen:
+        call `invalidate_plan()` after one."""
+        if dr is None:
+            return None
+        try:
+            if dr.is_inference():
+                return None
+            return (dr.data_ptr(), dr._version)
+        except RuntimeError:
+            return None
+
+    def invalidate_plan(self) -> None:
+        """Forget that the last prepare() built the dense schedule's plan: the next render rebuilds it from the depth prior as it
+        stands (use after changing `depth_range` in a way torch's version counter does not see)."""
+        self._plan_key = None
 
     # ---- next row N1: merge around the decoder ------------------------------------------------
     @_on_device
@@ -293,7 +319,7 @@ class HotPathEngine:
         if getattr(self, "_dec_ws", None) is None or self._dec_ws.numel() < need.value:
             self._dec_ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         b = self.cfg.bundle_size
-        rgb_c = self._buf("decode.rgb_c", (f.B, 3, f.H * b, f.W * b))
+        rgb_c = self._buf("decode.rgb_c", (f.B, 3, f.H * b, f.W * b), internal=True)
         _lib.check(self.lib.gdb_decode(C.byref(self.cfg), C.byref(f), bundle_feat.data_ptr(), int(bundle_feat.shape[1]), self.dec_weights.data_ptr(),
                                        self.dec_layers, int(precision), self._dec_ws.data_ptr(), self._dec_ws.numel(), rgb_c.data_ptr(), self._stream()))
         return rgb_c
@@ -353,8 +379,7 @@ class HotPathEngine:
     def _sched(self) -> int:
         """The schedule argument of a render call: this engine's schedule, plus the plan-is-current flag while the depth prior
         the last prepare() consumed is untouched."""
-        dr = self._keep.get("depth_range")
-        ready = self._plan_key is not None and dr is not None and (dr.data_ptr(), dr._version) == self._plan_key
+        ready = self._plan_key is not None and self._prior_key(self._keep.get("depth_range")) == self._plan_key
         return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0)
 
     @property
@@ -509,7 +534,7 @@ class HotPathEngine:
         nb = self.n_bundles
         if out is None:
             full = row_begin == 0 and row_end == f.H
-            out = self._buf("render.packed", (nb, self.Q + 2)) if full else torch.zeros((nb, self.Q + 2), device=self.device)
+            out = self._buf("render.packed", (nb, self.Q + 2), internal=True) if full else torch.zeros((nb, self.Q + 2), device=self.device)
         _chk(out, "out", (nb, self.Q + 2))
         _lib.check(self.lib.gdb_render_bundles_packed(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
                                                       int(row_begin), int(row_end), int(precision), self._sched(),

@@ -64,9 +64,11 @@ class Network(nn.Module):
         self.shard = str(getattr(nrf, "shard", "none"))
         if self.shard not in ("none", "rows"):
             raise ValueError(f"nerf.shard must be 'none' or 'rows', got {self.shard!r}")
-        # per-engine output buffers reused frame after frame (no allocation / memset in the per-frame path): the tensors in the
-        # returned dict are overwritten by the next forward; False returns fresh tensors
-        self.reuse_outputs = bool(getattr(nrf, "reuse_outputs", True))
+        # The intermediates of a frame (packed render, decoder image) always live in per-engine buffers reused frame after frame.
+        # The tensors in the returned dict are fresh by default, as the reference's are (a caller may keep them across frames);
+        # `nerf.reuse_outputs: true` makes them per-engine buffers too, overwritten by the next forward: no allocation at all in
+        # the per-frame path, for loops that consume a frame's outputs before the next one (bench.py, tools/bench_network.py).
+        self.reuse_outputs = bool(getattr(nrf, "reuse_outputs", False))
         self._feat_dim = feat_dim
         self._engine = None
         self._gather = None
@@ -80,6 +82,7 @@ class Network(nn.Module):
                                          hid_dim=self.nerf_hidden_dims, viewdir_agg=self.viewdir_agg, device=device)
         self._engine.precision = self.precision
         self._engine.reuse_outputs = self.reuse_outputs
+        self._engine.reuse_internal = True
         self.nerf.sync_engine(self._engine)
         if self.hip_decoder:
             # (storage, version) per tensor, as NeRF.param_versions: `p.data = ...` and load_state_dict(assign=True) change the

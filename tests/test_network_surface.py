@@ -156,6 +156,60 @@ def test_network_forward_matches_reference(f7, hot_path, precision, tol):
 
 
 @pytest.mark.gpu
+def test_forward_under_inference_mode_and_outputs_outlive_the_next_frame(f7):
+    """(1) tensors created under torch.inference_mode() have no version counter - the engine's plan key read
+    `depth_range._version` and Network.forward raised on every adaptive config; now such a prior simply makes the render rebuild
+    its plan (same image, bit for bit, as under no_grad, which is what the reference's run.py uses).  (2) the tensors forward
+    returns are fresh by default, as the reference's are: a second forward on other inputs leaves the first result untouched;
+    `nerf.reuse_outputs: true` is the opt-in that reuses them."""
+    net = _net(f7).cuda()
+    b1 = _batch(f7, "cuda")
+    with torch.no_grad():
+        r1 = net(b1)[0]
+        keep = {k: v.clone() for k, v in r1.items()}
+    with torch.inference_mode():
+        r2 = net(b1)[0]
+        assert all(torch.equal(r2[k], keep[k]) for k in keep)
+    b2 = _batch(f7, "cuda")
+    b2["src_views"]["rgb"] = b2["src_views"]["rgb"].flip(-1).contiguous()
+    with torch.no_grad():
+        r3 = net(b2)[0]
+    assert not torch.equal(r3["rgb"], keep["rgb"])
+    assert all(torch.equal(r1[k], keep[k]) for k in keep)           # the first frame's outputs are still the first frame's
+    assert all(torch.equal(r2[k], keep[k]) for k in keep)
+    reuse = _net(f7, **{"nerf.reuse_outputs": True}).cuda()
+    with torch.no_grad():
+        a = reuse(b1)[0]
+        assert all(torch.equal(a[k], keep[k]) for k in keep)
+        ptr = a["rgb"].data_ptr()
+        assert reuse(b2)[0]["rgb"].data_ptr() == ptr                   # the opt-in: one buffer, overwritten
+
+
+@pytest.mark.gpu
+def test_engine_plan_key_follows_unversioned_priors():
+    """HotPathEngine: an inference-mode depth prior never arms GDB_SCHED_PLAN_READY; invalidate_plan() disarms it for writes the
+    version counter cannot see (the key is armed only after gdb_prepare has returned OK)."""
+    from gdb_nerf_amd import synthetic, _lib
+    from gdb_nerf_amd.engine import HotPathEngine
+    fr = synthetic.make_frame(64, 80, V=3, seed=0)
+    eng = HotPathEngine(max_num_samples=3, is_adaptive=True)
+    eng.load_weights(synthetic.make_nerf_weights(seed=0))
+    dev = {k: torch.from_numpy(v).cuda() for k, v in fr.items()}
+    eng.prepare(dev)
+    assert eng._sched() & _lib.SCHED_PLAN_READY
+    want = eng.render()[0].clone()
+    eng.invalidate_plan()
+    assert not (eng._sched() & _lib.SCHED_PLAN_READY) and torch.equal(eng.render()[0], want)
+    with torch.inference_mode():
+        inf = {k: v.clone() for k, v in dev.items()}
+        eng.prepare(inf)
+        assert not (eng._sched() & _lib.SCHED_PLAN_READY)
+        assert torch.equal(eng.render()[0], want)
+    eng.prepare(dev)
+    assert eng._sched() & _lib.SCHED_PLAN_READY
+
+
+@pytest.mark.gpu
 def test_sharded_forward_at_world_1_is_bit_identical(f7):
     """`nerf.shard: rows` with a one-rank process group takes the sharded branch (render the strip into the gather buffer, gather,
     replicated decoder + merge) and must reproduce the unsharded forward bit for bit; two forwards reuse the same buffers."""

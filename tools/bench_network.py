@@ -19,7 +19,7 @@ for name, opts in {"fused (fp32 MFMA) + hip cost volume + hip decoder [default]"
                    "fused, torch cost volume, torch decoder": ["mvs.hip_cost_volume", "False", "nerf.hip_decoder", "False"],
                    "operator mirrors + hip cost volume, torch decoder": ["nerf.hot_path", "mirrors", "nerf.hip_decoder", "False"]}.items():
     torch.manual_seed(0)
-    net = make_network(make_cfg("configs/dtu_eval.yaml", opts)).eval().cuda()
+    net = make_network(make_cfg("configs/dtu_eval.yaml", opts + ["nerf.reuse_outputs", "True"])).eval().cuda()
     times = []
     with torch.no_grad():
         for i in range(16):
