@@ -62,6 +62,44 @@ def main():
     path = os.path.join(HERE, "F7_network.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; keys in state dict:", len(sd))
+    more(net, RefNetwork)
+
+
+def _prepared(RefNetwork, yaml, ref_sd):
+    """The reference's Network under another YAML with F7's weights (same architecture: the state dicts must agree key by key)."""
+    torch.manual_seed(0)
+    net = RefNetwork(make_cfg(yaml)).eval()
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref_sd.items()], yaml
+    net.load_state_dict(ref_sd, strict=True)
+    return net
+
+
+def more(net7, RefNetwork):
+    """Two more pins of the call site, weights shared with F7 so that the fixtures hold inputs and outputs only:
+    F7b - `configs/nerf_eval.yaml` (reweighting: True, S_max 6 adaptive; network.py:181-182) on a NeRF-synthetic-like frame;
+    F7c - `configs/dtu_eval.yaml` with batch['render_scale'] = 0.5 (network.py:125-131) on a 128x192 input rendered at 64x96."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd = {k: v.clone() for k, v in net7.state_dict().items()}
+    for tag, yaml, frame, scale in (("F7b_network_nerf_eval", "configs/nerf_eval.yaml", synthetic.make_frame(64, 96, V=3, B=1, scene="nerf", seed=11), None),
+                                    ("F7c_network_render_scale", "configs/dtu_eval.yaml", synthetic.make_frame(128, 192, V=3, B=1, seed=12), 0.5)):
+        net = _prepared(RefNetwork, yaml, sd)
+        frame["src_images"] = frame["src_images"].astype(np.float16).astype(np.float32)   # stored as halves: both sides read these values
+        batch = {"src_views": {"rgb": t(frame["src_images"]), "extrinsics": t(frame["src_exts"]), "intrinsics": t(frame["src_ints"])},
+                 "tar_views": {"extrinsics": t(frame["tar_ext"]), "intrinsics": t(frame["tar_int"])},
+                 "near_far": t(frame["near_far"])}
+        if scale is not None:
+            batch["render_scale"] = torch.tensor([scale])
+        with torch.no_grad():
+            ret, mvs_depths, blend = net(batch)
+        out = dict(src_images=frame["src_images"].astype(np.float16), src_exts=frame["src_exts"], src_ints=frame["src_ints"],
+                   tar_ext=frame["tar_ext"], tar_int=frame["tar_int"], near_far=frame["near_far"],
+                   rgb=ret["rgb"].numpy(), nerf_depth=ret["nerf_depth"].numpy(), mvs_depth=ret["mvs_depth"].numpy(),
+                   opacity=ret["opacity"].numpy(), yaml=np.array(yaml), render_scale=np.float32(scale if scale is not None else 1.0),
+                   reweighting=np.bool_(net.reweighting), max_num_samples=np.int32(net.max_num_samples))
+        path = os.path.join(HERE, tag + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB; rgb", tuple(ret["rgb"].shape), "reweighting", net.reweighting,
+              "S_max", net.max_num_samples, "render_scale", scale)
 
 
 if __name__ == "__main__":

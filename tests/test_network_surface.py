@@ -156,6 +156,38 @@ def test_network_forward_matches_reference(f7, hot_path, precision, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["F7b_network_nerf_eval", "F7c_network_render_scale"])
+@pytest.mark.parametrize("hot_path,precision,tol", [("mirrors", "f32", 5e-4), ("fused", "f32", 5e-4), ("fused", "f32x", 5e-4), ("fused", "f16", 2e-3)])
+def test_network_forward_matches_reference_on_the_other_branches(f7, fixture, hot_path, precision, tol):
+    """The two branches of the call site F7 does not reach, pinned by the reference's own Network (tests/golden/make_golden_network.py,
+    weights shared with F7): F7b = configs/nerf_eval.yaml - `reweighting: True` (network.py:181-182: img = 0.5 (img + rgb_f)) with
+    S_max 6 adaptive on a NeRF-synthetic-like frame; F7c = configs/dtu_eval.yaml with batch['render_scale'] = 0.5 (network.py:125-131:
+    sources resized, intrinsics scaled, a 128x192 input rendered at 64x96)."""
+    fx = load_golden(fixture)
+    flat = ["nerf.hot_path", hot_path, "nerf.precision", precision]
+    net = make_network(make_cfg(str(fx["yaml"]), flat)).eval()
+    net.load_state_dict(_state_dict(f7), strict=True)
+    net = net.cuda()
+    assert net.reweighting == bool(fx["reweighting"]) and net.max_num_samples == int(fx["max_num_samples"])
+    fxb = dict(fx); fxb["src_images"] = fx["src_images"].astype(np.float32)
+    batch = _batch(fxb, "cuda")
+    if float(fx["render_scale"]) != 1.0:
+        batch["render_scale"] = torch.tensor([float(fx["render_scale"])], device="cuda")
+    with torch.no_grad():
+        ret, mvs_depths, blend = net(batch)
+    assert tuple(ret["rgb"].shape) == tuple(fx["rgb"].shape) == (1, 3, 64, 96)
+    e = max_abs(ret["rgb"].cpu().numpy(), fx["rgb"])
+    print(f"{fixture} ({hot_path}, {precision}): max |rgb - reference| = {e:.3e}")
+    assert e <= tol
+    assert max_abs(ret["mvs_depth"].cpu().numpy(), fx["mvs_depth"]) <= 1e-3 * float(np.abs(fx["mvs_depth"]).max())
+    assert max_abs(ret["nerf_depth"].cpu().numpy(), fx["nerf_depth"]) <= 2e-3 * float(np.abs(fx["nerf_depth"]).max())
+    assert max_abs(ret["opacity"].cpu().numpy(), fx["opacity"]) <= 1e-4
+    gt = np.clip(np.transpose(fx["rgb"][0], (1, 2, 0)) + np.random.default_rng(1).normal(0, 0.03, (64, 96, 3)), 0, 1)
+    d_psnr = abs(oracle.psnr(gt, np.transpose(ret["rgb"][0].cpu().numpy(), (1, 2, 0))) - oracle.psnr(gt, np.transpose(fx["rgb"][0], (1, 2, 0))))
+    assert d_psnr <= 0.05
+
+
+@pytest.mark.gpu
 def test_forward_under_inference_mode_and_outputs_outlive_the_next_frame(f7):
     """(1) tensors created under torch.inference_mode() have no version counter - the engine's plan key read
     `depth_range._version` and Network.forward raised on every adaptive config; now such a prior simply makes the render rebuild
