@@ -191,8 +191,11 @@ def cpu_baseline(wl, frame, weights, quick=False):
     c1_rows = []
     for threads in ([8] if quick else sorted({8, ncpu})):
         torch.set_num_threads(threads)
-        s1 = timed(lambda: gdb_oracle_torch.hot_path(f1, weights, max_num_samples=c1["S"], is_adaptive=c1["adaptive"]))
-        c1_rows.append({"workload": "c1 64x80", "impl": "torch", "threads": threads, "value": c1["Ho"] * c1["Wo"] / s1, "s_per_frame": s1})
+        fn1 = lambda: gdb_oracle_torch.hot_path(f1, weights, max_num_samples=c1["S"], is_adaptive=c1["adaptive"])
+        t0 = time.perf_counter(); fn1(); first = time.perf_counter() - t0
+        # (all hardware threads of a 256-thread host: 13 s for ONE 64x80 frame, oversubscribed - taken once, not averaged)
+        s1, note = (timed(fn1), "mean of 2 frames after 2 dropped") if first <= 2.0 else (first, "ONE frame (it took more than 2 s: not repeated)")
+        c1_rows.append({"workload": "c1 64x80", "impl": "torch", "threads": threads, "value": c1["Ho"] * c1["Wo"] / s1, "s_per_frame": s1, "frames": note})
     torch.set_num_threads(before)
     if not quick:
         sn = timed(lambda: gdb_oracle.hot_path(frame, weights, **kw), reps=2)

@@ -772,17 +772,18 @@ def test_fused_matches_fp32_chain_at_baseline_sizes(name, Ho, Wo, V, S, adaptive
     assert torch.equal(eng.render()[0], bf)                  # repeatable bit for bit
 
 
+@pytest.mark.parametrize("offset", [30.0, 100.0])
 @pytest.mark.parametrize("sched", [1, 2, 3], ids=["slot-waves", "segment-wave", "dense"])
-def test_fp32_variance_over_views_on_large_magnitude_features(sched):
+def test_fp32_variance_over_views_on_large_magnitude_features(sched, offset):
     """the reference's `torch.var_mean` over the views (nerf.py:73) is two-pass; the fp32 core's one-pass form
     accumulates around a shift (d = g_v - g_0), so its cancellation is relative to the spread of g over the views, not to |g|^2.
-    Features scaled x30 (|g| ~ 100, as the unnormalised FPN output of a real checkpoint can be) with three nearly identical source
-    views - a small variance under a large mean, where sum(g^2) - V mean^2 loses its digits - against the oracle."""
+    Every view's feature channels carry a common offset of +-30 / +-100 (unnormalised FPN features of a real checkpoint: a large
+    mean under an O(1) spread over the views, where sum(g^2) - V mean^2 loses digits): fused fp32 against the oracle, relative to
+    the output's scale.  (On the CPU restatement the plain sum-of-squares form moves the output by 8e-7 of its scale at offset 100,
+    the shifted form by 3e-7 = the two-pass value; end to end the bound below is set by the fp32 fetch noise.)"""
     frame = synthetic.make_frame(64, 96, V=3, B=1, seed=13)
-    f = frame["img_feat"]
-    f[:, 1] = f[:, 0] + 1e-2 * f[:, 1]          # views 1, 2 = view 0 plus a small perturbation: variance 1e-4 of the mean's square
-    f[:, 2] = f[:, 0] - 1e-2 * f[:, 2]
-    frame["img_feat"] = (f * np.float32(30.0)).astype(np.float32)
+    c = (offset * np.random.default_rng(3).choice([-1.0, 1.0], size=(1, 1, 16, 1, 1))).astype(np.float32)
+    frame["img_feat"][:, :, :16] += c
     w = synthetic.make_nerf_weights(seed=5)
     with np.errstate(all="ignore"):
         obf, od, oo = oracle.hot_path(frame, w, max_num_samples=3, is_adaptive=True)
@@ -791,8 +792,8 @@ def test_fp32_variance_over_views_on_large_magnitude_features(sched):
     scale = float(np.abs(obf).max())
     e = max_abs(bf, obf) / scale
     eu = max_abs(npy(eng.render_unfused()[0]), obf) / scale
-    print(f"features x30, near-identical views, schedule {sched}: output scale {scale:.3g}; fused fp32 vs oracle {e:.2e} of it (operator chain {eu:.2e})")
-    assert e <= 2e-5 and eu <= 2e-5
+    print(f"feature offset {offset}, schedule {sched}: output scale {scale:.3g}; fused fp32 vs oracle {e:.2e} of it (operator chain {eu:.2e})")
+    assert e <= 1e-5 and eu <= 1e-5
 
 
 @pytest.mark.parametrize("name,Ho,Wo,V,S,adaptive,scene,precs", [("c3p 756x1008", 756, 1008, 3, 3, True, "llff", (1,)),
