@@ -12,10 +12,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # GDB_NERF_LIB selects another build of the same ABI (tools/: the -DGDB_DIAG diagnostic library and A/B flag variants are
 # built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
 SCHED_PLAN_READY = 0x100
+SCHED_PYR16_READY = 0x200
+PREP_PYR16 = 1
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8
@@ -51,6 +53,8 @@ _SIGNATURES = {
     "gdb_pack_weights": (C.c_int, [_CFG, C.POINTER(_P), _P]),
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),
     "gdb_prepare_fpn": (C.c_int, [_CFG, _FRM, _P, _P, C.c_size_t, _P]),
+    "gdb_prepare_ex": (C.c_int, [_CFG, _FRM, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "gdb_pyramid16_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_build_rays": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P]),
     "gdb_sample": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gdb_encode": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

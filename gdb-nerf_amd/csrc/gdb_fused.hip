@@ -22,12 +22,14 @@
 //                contiguous run per segment.
 #include "gdb_internal.h"
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 
 int gdb_fail(int code, const char* fmt, ...);
 int gdb_check_cfg(const GdbConfig* c);
 int gdb_check_frame(const GdbConfig* c, const GdbFrame* f, bool need_ptrs);
 int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st);
+int gdb_build_pyr16(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st);
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -586,6 +588,48 @@ __device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4
     acc[2].y = fmaf(d.u[3].y, t.w11, fmaf(d.u[2].y, t.w01, fmaf(d.u[1].y, t.w10, ay)));
 }
 
+// ---- the same taps from the half-precision pyramid (GDB_PREC_F16; gdb_internal.h PYR16_*) -----------------------------------
+// Half h reads ONE 16-byte texel of plane h (channels 4h..4h+3 | 8+4h..8+4h+3) and ONE 4-byte pair of plane 2 (channels 16+2h,
+// 17+2h) per tap: two load instructions where the fp32 pyramid takes three, 20 bytes where it takes 40.  Products accumulate in
+// fp32 (v_fma_mix_f32 reads the half straight out of the loaded register: no conversion instruction).
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+struct Taps16 { unsigned p00, p10, p01, p11, lvlB, hw; float w00, w10, w01, w11; };  // texel indices, byte offset of the level, texels per plane
+__device__ __forceinline__ Taps16 make_taps16(float u, float v, int W, int H, unsigned lvlB, float lw) {
+    int x0, x1, y0, y1; float fx, fy;
+    tex_coord(u, W, x0, x1, fx);
+    tex_coord(v, H, y0, y1, fy);
+    Taps16 t;
+    const unsigned r0 = __umul24(y0, W), r1 = __umul24(y1, W);
+    t.p00 = r0 + x0; t.p10 = r0 + x1; t.p01 = r1 + x0; t.p11 = r1 + x1;
+    t.lvlB = lvlB; t.hw = __umul24(W, H);
+    const float ex = (1.f - fx) * lw, wx = fx * lw;
+    t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
+    return t;
+}
+struct TapData16 { half8v q[4]; half2v u[4]; };
+__device__ __forceinline__ void taps_load16(const void* __restrict__ pyr16, const Taps16& t, int h, TapData16& d) {
+    const unsigned b0 = t.lvlB + (h ? 16u * t.hw : 0u), b2 = t.lvlB + PYR16_PLANE2(t.hw) + 4u * (unsigned)h;
+    d.q[0] = ldu<half8v>(pyr16, b0 + 16u * t.p00); d.q[1] = ldu<half8v>(pyr16, b0 + 16u * t.p10);
+    d.q[2] = ldu<half8v>(pyr16, b0 + 16u * t.p01); d.q[3] = ldu<half8v>(pyr16, b0 + 16u * t.p11);
+    d.u[0] = ldu<half2v>(pyr16, b2 + 8u * t.p00); d.u[1] = ldu<half2v>(pyr16, b2 + 8u * t.p10);
+    d.u[2] = ldu<half2v>(pyr16, b2 + 8u * t.p01); d.u[3] = ldu<half2v>(pyr16, b2 + 8u * t.p11);
+}
+template <bool INIT>
+__device__ __forceinline__ void taps_acc16(const Taps16& t, const TapData16& d, float4 acc[3]) {
+    const float w[4] = {t.w00, t.w10, t.w01, t.w11};
+    float* a0 = (float*)&acc[0]; float* a1 = (float*)&acc[1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0[e] = (INIT && k == 0) ? (float)d.q[k][e] * w[k] : fmaf((float)d.q[k][e], w[k], a0[e]);
+            a1[e] = (INIT && k == 0) ? (float)d.q[k][4 + e] * w[k] : fmaf((float)d.q[k][4 + e], w[k], a1[e]);
+        }
+        acc[2].x = (INIT && k == 0) ? (float)d.u[k].x * w[k] : fmaf((float)d.u[k].x, w[k], acc[2].x);
+        acc[2].y = (INIT && k == 0) ? (float)d.u[k].y * w[k] : fmaf((float)d.u[k].y, w[k], acc[2].y);
+    }
+}
+
 // Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
 typedef float F2v __attribute__((ext_vector_type(2)));
 typedef F2v F2u __attribute__((aligned(4)));  // a vector type, so it can be loaded through any address space
@@ -695,6 +739,8 @@ __device__ __forceinline__ void view_dir_code(const float ctr[3], const float* _
 
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
+// P16: the feature taps come from the half-precision pyramid (GDB_PREC_F16).
+template <bool P16>
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float* __restrict__ tc, float4 feat[3], float dir[4], float rgb[2][3], int skip) {
     float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: scalar loads (of the entries used below), the block lives in SGPRs
@@ -726,13 +772,22 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
-    const float* pyr = f.pyr + ((size_t)bi * f.V + v) * f.pyrStride;
+    // (the half-precision copy has the same element offsets: 2 bytes per element instead of 4)
+    const void* pyr = P16 ? (const void*)((const char*)f.pyr16 + ((size_t)bi * f.V + v) * f.pyrStride * 2)
+                          : (const void*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
     // level offsets as register values: left as f.lvlOff[...] selects, the compiler selects the *address* and
     // issues a per-lane load from kernarg memory (a full vector-memory round trip for a constant)
     unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
     asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
     const unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
-    const Taps t0 = make_taps(tu, tvv, f.W >> l0, f.H >> l0, o0 << 2, 1.f - frac);
+    typedef typename std::conditional<P16, Taps16, Taps>::type TapsT;
+    typedef typename std::conditional<P16, TapData16, TapData>::type TapDataT;
+    auto mk = [&](int l, unsigned off, float lw) {
+        if constexpr (P16) return make_taps16(tu, tvv, f.W >> l, f.H >> l, off << 1, lw);
+        else return make_taps(tu, tvv, f.W >> l, f.H >> l, off << 2, lw);
+    };
+    auto ld = [&](const TapsT& t, TapDataT& d) { if constexpr (P16) taps_load16(pyr, t, h, d); else taps_load(pyr, t, h, d); };
+    const TapsT t0 = mk(l0, o0, 1.f - frac);
     const bool two = frac > 0.f && do_tex;
     RgbTaps rt[2];
 #pragma unroll
@@ -745,23 +800,23 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         rt[e] = rgb_taps(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
     }
     // ---- issue: level 0 and both sub-rays' colours in flight together -------------------------------
-    TapData d0, d1;
+    TapDataT d0, d1;
     RgbData rd[2];
-    if (do_tex) taps_load(pyr, t0, h, d0);
+    if (do_tex) ld(t0, d0);
     const unsigned plane = (unsigned)(f.Ho * f.Wo);
     if (do_rgb) { rgb_load(img, plane, rt[0], rd[0]); rgb_load(img, plane, rt[1], rd[1]); }
     // ---- consume level 0, issue level 1, consume the colours under its latency, consume level 1 -------
-    if (do_tex) taps_acc<true>(t0, d0, feat);
+    if (do_tex) { if constexpr (P16) taps_acc16<true>(t0, d0, feat); else taps_acc<true>(t0, d0, feat); }
     else feat[0] = feat[1] = feat[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    Taps t1 = t0;
+    TapsT t1 = t0;
     if (two) {
         const unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
-        t1 = make_taps(tu, tvv, f.W >> l1, f.H >> l1, o1 << 2, frac);
-        taps_load(pyr, t1, h, d1);
+        t1 = mk(l1, o1, frac);
+        ld(t1, d1);
     }
     if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
     else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
-    if (two) taps_acc<false>(t1, d1, feat);
+    if (two) { if constexpr (P16) taps_acc16<false>(t1, d1, feat); else taps_acc<false>(t1, d1, feat); }
     view_dir_code(ctr, tc + T_O, sc + S_C, dir);
 }
 
@@ -827,7 +882,7 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
         // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
         float dir[4], rgb[2][3];
-        if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, tc, feat, dir, rgb, skip);
+        if (act) gather_view<PREC == GDB_PREC_F16>(f, bi, v, h, xyzh, ctr, ball, tc, feat, dir, rgb, skip);
         else {
             const float u = __builtin_nondeterministic_value(0.f);
             feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
@@ -2142,8 +2197,8 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
     if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X)
         return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA, 2 = split-f16 operands)", precision);
-    const bool plan_ready = (schedule & GDB_SCHED_PLAN_READY) != 0;
-    schedule &= ~GDB_SCHED_PLAN_READY;
+    const bool plan_ready = (schedule & GDB_SCHED_PLAN_READY) != 0, pyr16_ready = (schedule & GDB_SCHED_PYR16_READY) != 0;
+    schedule &= ~(GDB_SCHED_PLAN_READY | GDB_SCHED_PYR16_READY);
     if (schedule < 0 || schedule > 3) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..3", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
@@ -2170,6 +2225,13 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.skip = env_skip; a.dbg = g_dbg;
 #endif
     hipStream_t st = (hipStream_t)stream_;
+    // GDB_PREC_F16 gathers its feature taps from the half-precision copy of the pyramid: made here (a launch of its own on the same
+    // stream, from the fp32 pyramid) unless the caller vouches that gdb_prepare_ex(GDB_PREP_PYR16) made it for this frame
+    if (precision == GDB_PREC_F16 && !pyr16_ready) {
+        if (L.pyrStride * 2 >= lim) return gdb_fail(GDB_E_SHAPE, "frame too large for the fused kernel: a per-view pyramid exceeds 4 GiB");
+        rc = gdb_build_pyr16(cfg, fr, const_cast<void*>(ws), st);
+        if (rc) return rc;
+    }
     if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, plan_ready, st);
     if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, ws, schedule, plan_ready, st);
     return render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, plan_ready, st);

@@ -110,6 +110,16 @@ extern "C" int gdb_pyramid_layout(const GdbConfig* cfg, const GdbFrame* shape, s
     return GDB_OK;
 }
 
+extern "C" int gdb_pyramid16_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, shape, false); if (rc) return rc;
+    if (!out) return gdb_fail(GDB_E_BADARG, "out is NULL");
+    const WsLayout L = ws_layout(*cfg, *shape);
+    out[0] = L.pyr16Off; out[1] = 2 * L.pyrStride; out[2] = (size_t)L.levels;   // byte offset, bytes per (batch, view), levels
+    for (int l = 0; l <= GDB_MAX_MIP; ++l) out[3 + l] = l <= L.levels ? 2 * L.lvlOff[l] : 0;  // byte offset of each level
+    return GDB_OK;
+}
+
 // ============================================================================================
 // camera block
 // ============================================================================================
@@ -208,6 +218,7 @@ struct PrepArgs {
     unsigned lvlOff[GDB_MAX_MIP + 1];
     unsigned pyrStride;
     const float* img_feat; float* pyr;
+    char* pyr16;  // half-precision copy of the pyramid (gdb_internal.h PYR16_*), or NULL: not asked for
     const float* src_images; int Ho, Wo, fpn;  // fpn: img_feat holds C_f channels only; the 3 colours are resampled here (N3)
     const float* tar_exts; const float* tar_ints; const float* src_exts; const float* src_ints; const float* near_far;
     float* cams;
@@ -330,6 +341,16 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
     return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
 }
 
+// ---- half-precision pyramid stores (GDB_PREP_PYR16) ------------------------------------------------------------------------------
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h4v to_h4(const float4 q) { return h4v{(_Float16)q.x, (_Float16)q.y, (_Float16)q.z, (_Float16)q.w}; }
+// fp32 chunk c (channels 4c..4c+3) of texel p of a level of hw texels at byte offset lvlB: plane c & 1, second 8 bytes of the texel
+// for c >= 2; chunk 4 = plane 2 (8 bytes per texel)
+__device__ __forceinline__ void store16_chunk(char* __restrict__ base, unsigned lvlB, unsigned hw, unsigned p, int c, const float4 q) {
+    const unsigned off = c == 4 ? lvlB + PYR16_PLANE2(hw) + 8u * p : lvlB + (unsigned)(c & 1) * 16u * hw + 16u * p + (unsigned)(c >> 1) * 8u;
+    *(h4v*)(base + off) = to_h4(q);
+}
+
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
     static_assert(sizeof(tile4) >= 4 * 128 * sizeof(unsigned) && PLAN_LDS_ROW <= 128 * 32, "the plan rows borrow the tile's LDS: 128 words of start bits per row");
@@ -382,11 +403,24 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     }
     v[GDB_CFR] = 0.f;
     float4* pyr4 = (float4*)(a.pyr + (size_t)bv * a.pyrStride);
+    char* p16 = a.pyr16 ? a.pyr16 + (size_t)bv * 2 * a.pyrStride : nullptr;
 #pragma unroll
     for (int c = 0; c < GDB_CP / 4; ++c) {
         const float4 q = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
         tile4[(c * PT_H + ly) * PT_W + lx] = q;                           // texels outside the map are zero
         if (in0) pyr4[((size_t)c * a.H + gy) * a.W + gx] = q;
+    }
+    if (p16 && in0) {  // level 0 of the half-precision copy: the texel's two 16-byte planes and its 8-byte plane, straight from registers
+        typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+        const unsigned hw = (unsigned)(a.H * a.W), p = (unsigned)(gy * a.W + gx);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            h8v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (_Float16)v[4 * hh + e]; o[4 + e] = (_Float16)v[8 + 4 * hh + e]; }
+            *(h8v*)(p16 + (size_t)hh * 16u * hw + 16u * p) = o;
+        }
+        *(h4v*)(p16 + PYR16_PLANE2(hw) + 8u * p) = h4v{(_Float16)v[16], (_Float16)v[17], (_Float16)v[18], (_Float16)v[19]};
     }
     if (a.levels < 1) return;
     __syncthreads();
@@ -403,13 +437,19 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
             const int sx = 4 * bx + 2 * i2, sy = 4 * by + 2 * j2;
             l1[j2][i2] = box4(T[sy * PT_W + sx], T[sy * PT_W + sx + 1], T[(sy + 1) * PT_W + sx], T[(sy + 1) * PT_W + sx + 1]);
             const int px = (x0 >> 1) + 2 * bx + i2, py = (y0 >> 1) + 2 * by + j2;
-            if (px < a.lvlW[1] && py < a.lvlH[1]) pyr4[(a.lvlOff[1] >> 2) + ((size_t)ch * a.lvlH[1] + py) * a.lvlW[1] + px] = l1[j2][i2];
+            if (px < a.lvlW[1] && py < a.lvlH[1]) {
+                pyr4[(a.lvlOff[1] >> 2) + ((size_t)ch * a.lvlH[1] + py) * a.lvlW[1] + px] = l1[j2][i2];
+                if (p16) store16_chunk(p16, 2u * a.lvlOff[1], (unsigned)(a.lvlH[1] * a.lvlW[1]), (unsigned)(py * a.lvlW[1] + px), ch, l1[j2][i2]);
+            }
         }
     if (a.levels < 2) return;
     const float4 l2 = box4(l1[0][0], l1[0][1], l1[1][0], l1[1][1]);
     {
         const int px = (x0 >> 2) + bx, py = (y0 >> 2) + by;
-        if (px < a.lvlW[2] && py < a.lvlH[2]) pyr4[(a.lvlOff[2] >> 2) + ((size_t)ch * a.lvlH[2] + py) * a.lvlW[2] + px] = l2;
+        if (px < a.lvlW[2] && py < a.lvlH[2]) {
+            pyr4[(a.lvlOff[2] >> 2) + ((size_t)ch * a.lvlH[2] + py) * a.lvlW[2] + px] = l2;
+            if (p16) store16_chunk(p16, 2u * a.lvlOff[2], (unsigned)(a.lvlH[2] * a.lvlW[2]), (unsigned)(py * a.lvlW[2] + px), ch, l2);
+        }
     }
     if (a.levels < 3) return;
     // the level-2 neighbours (bx^1, by), (bx, by^1), (bx^1, by^1) sit in lanes t^1, t^8, t^9 of the same 16-lane group
@@ -417,11 +457,41 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     if ((bx & 1) == 0 && by == 0) {
         const float4 l3 = box4(l2, nb, nc, nd);
         const int px = (x0 >> 3) + (bx >> 1), py = y0 >> 3;
-        if (px < a.lvlW[3] && py < a.lvlH[3]) pyr4[(a.lvlOff[3] >> 2) + ((size_t)ch * a.lvlH[3] + py) * a.lvlW[3] + px] = l3;
+        if (px < a.lvlW[3] && py < a.lvlH[3]) {
+            pyr4[(a.lvlOff[3] >> 2) + ((size_t)ch * a.lvlH[3] + py) * a.lvlW[3] + px] = l3;
+            if (p16) store16_chunk(p16, 2u * a.lvlOff[3], (unsigned)(a.lvlH[3] * a.lvlW[3]), (unsigned)(py * a.lvlW[3] + px), ch, l3);
+        }
     }
 }
 
-static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, void* ws, size_t ws_bytes, void* stream_);
+// The half-precision copy alone, from the fp32 pyramid an earlier gdb_prepare built (a GDB_PREC_F16 render that is not told the
+// copy exists - GDB_SCHED_PYR16_READY - makes it first): one thread per (texel of any level, fp32 chunk).
+__global__ void __launch_bounds__(256) k_pyr16(const float* __restrict__ pyr, char* __restrict__ pyr16, unsigned pyrStride, int nbv, int levels,
+                                               int H, int W, unsigned lo1, unsigned lo2, unsigned lo3) {
+    const unsigned per = pyrStride / 4;                       // float4 chunks per (batch, view)
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)per * nbv) return;
+    const unsigned bv = (unsigned)(t / per), q = (unsigned)(t % per);
+    // which level: chunk-planar blocks of 5 hw_l float4s at float4 offset lvlOff[l] / 4
+    int l = 0; unsigned lo = 0;
+    if (levels >= 1 && q >= lo1 / 4) { l = 1; lo = lo1; }
+    if (levels >= 2 && q >= lo2 / 4) { l = 2; lo = lo2; }
+    if (levels >= 3 && q >= lo3 / 4) { l = 3; lo = lo3; }
+    const unsigned hw = (unsigned)((H >> l) * (W >> l)), r = q - lo / 4, c = r / hw, p = r % hw;
+    if (c >= 5) return;
+    const float4 v = ((const float4*)(pyr + (size_t)bv * pyrStride))[q];
+    store16_chunk(pyr16 + (size_t)bv * 2 * pyrStride, 2u * lo, hw, p, (int)c, v);
+}
+int gdb_build_pyr16(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st) {
+    WsLayout L = ws_layout(*cfg, *f);
+    const size_t n = (L.pyrStride / 4) * (size_t)f->B * f->V;
+    hipLaunchKernelGGL(k_pyr16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)((char*)ws + L.pyrOff), (char*)ws + L.pyr16Off,
+                       (unsigned)L.pyrStride, f->B * f->V, L.levels, f->H, f->W, (unsigned)L.lvlOff[1], (unsigned)L.lvlOff[2], (unsigned)L.lvlOff[3]);
+    LAUNCH_CHECK("k_pyr16");
+    return GDB_OK;
+}
+
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_);
 
 // The dense plan alone (for a render call that asks for GDB_SCHED_DENSE on a frame whose prepare did not build it).
 __global__ void __launch_bounds__(256) k_plan(PrepArgs a) {
@@ -442,16 +512,22 @@ int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipS
 }
 
 extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, size_t ws_bytes, void* stream_) {
-    return prepare_common(cfg, f, nullptr, ws, ws_bytes, stream_);
+    return prepare_common(cfg, f, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+extern "C" int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, int32_t flags, void* ws, size_t ws_bytes, void* stream_) {
+    if (flags & ~GDB_PREP_PYR16) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: unknown flag bits 0x%x", (unsigned)(flags & ~GDB_PREP_PYR16));
+    if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex with d_fpn_feat resamples frame->d_src_images: it is NULL");
+    return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_);
 }
 
 extern "C" int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, void* ws, size_t ws_bytes, void* stream_) {
     if (!d_fpn_feat) return gdb_fail(GDB_E_BADARG, "d_fpn_feat is NULL");
     if (!f || !f->d_src_images) return gdb_fail(GDB_E_BADARG, "gdb_prepare_fpn resamples frame->d_src_images: it is NULL");
-    return prepare_common(cfg, f, d_fpn_feat, ws, ws_bytes, stream_);
+    return prepare_common(cfg, f, d_fpn_feat, 0, ws, ws_bytes, stream_);
 }
 
-static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, void* ws, size_t ws_bytes, void* stream_) {
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
     if (!ws) return gdb_fail(GDB_E_BADARG, "workspace is NULL");
@@ -471,6 +547,9 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { a.lvlH[i] = L.lvlH[i]; a.lvlW[i] = L.lvlW[i]; a.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     a.pyrStride = (unsigned)L.pyrStride;
     a.img_feat = fpn_feat ? fpn_feat : f->d_img_feat; a.pyr = (float*)((char*)ws + L.pyrOff);
+    a.pyr16 = (flags & GDB_PREP_PYR16) ? (char*)ws + L.pyr16Off : nullptr;
+    // the half-precision copy is addressed with 32-bit byte offsets inside one (batch, view) block
+    if (a.pyr16 && (size_t)2 * L.pyrStride >= ((size_t)1 << 32)) return gdb_fail(GDB_E_SHAPE, "feature map too large for the half-precision pyramid");
     a.fpn = fpn_feat != nullptr; a.src_images = f->d_src_images; a.Ho = f->Ho; a.Wo = f->Wo;
     a.tar_exts = f->d_tar_exts; a.tar_ints = f->d_tar_ints; a.src_exts = f->d_src_exts; a.src_ints = f->d_src_ints;
     a.near_far = f->d_near_far; a.cams = (float*)((char*)ws + L.camsOff);

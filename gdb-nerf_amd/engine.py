@@ -90,6 +90,7 @@ class HotPathEngine:
         self._keep: Dict[str, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self._plan_key = None
+        self._pyr16_ready = False
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
         self.reuse_outputs = False
@@ -208,10 +209,13 @@ class HotPathEngine:
                 # DESIGN.md §2, "odd-extent rule": a level is built only while both extents of the one below are even and >= 2
                 warnings.warn(f"feature map {H}x{W}: the mip chain stops at level {self.mip_levels} (an extent turns odd), below "
                               f"nerf.max_mipmap_level = {self.cfg.max_mipmap_level}; footprints are clamped to that level")
-        if fpn is not None:
-            _lib.check(self.lib.gdb_prepare_fpn(C.byref(self.cfg), C.byref(f), fpn.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._stream()))
-        else:
-            _lib.check(self.lib.gdb_prepare(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        # an engine whose precision is PREC_F16 has the half-precision copy of the pyramid written in the same launch (the f16 render
+        # gathers from it); any other engine that is asked for an f16 render later lets that render convert the fp32 pyramid itself
+        self._pyr16_ready = False
+        flags = _lib.PREP_PYR16 if (self.precision == _lib.PREC_F16 and "src_images" in frame) else 0
+        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), None if fpn is None else fpn.data_ptr(), flags,
+                                           self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        self._pyr16_ready = bool(flags)
         if self.cfg.is_adaptive:
             self._plan_key = self._prior_key(frame.get("depth_range"))
         return self.mip_levels
@@ -348,6 +352,26 @@ class HotPathEngine:
             res.append(lv.permute(0, 2, 3, 1, 4).reshape(f.B, f.V, h, w, 20)[..., :19].contiguous())
         return res
 
+    def feature_pyramid16(self):
+        """The HALF-precision copy of the pyramid (what a PREC_F16 render gathers from), per level (B, V, H_l, W_l, C_f+3) float16
+        (copies).  Only meaningful after a prepare() of a PREC_F16 engine or after an f16 render (which builds it on demand)."""
+        f = self._need_frame()
+        out = (C.c_size_t * 7)()
+        _lib.check(self.lib.gdb_pyramid16_layout(C.byref(self.cfg), C.byref(f), out))
+        off, stride, levels = out[0], out[1], out[2]
+        n = f.B * f.V
+        blk = self._ws[off:off + stride * n].view(n, stride)
+        res = []
+        for l in range(levels + 1):
+            h, w = f.H >> l, f.W >> l
+            hw, lo = h * w, out[3 + l]
+            p0 = blk[:, lo:lo + 16 * hw].contiguous().view(torch.float16).view(n, hw, 8)            # channels 0..3, 8..11
+            p1 = blk[:, lo + 16 * hw:lo + 32 * hw].contiguous().view(torch.float16).view(n, hw, 8)  # channels 4..7, 12..15
+            p2 = blk[:, lo + 32 * hw:lo + 40 * hw].contiguous().view(torch.float16).view(n, hw, 4)  # channels 16..19
+            lv = torch.cat((p0[..., :4], p1[..., :4], p0[..., 4:], p1[..., 4:], p2), dim=-1)        # (n, hw, 20)
+            res.append(lv.view(f.B, f.V, h, w, 20)[..., :19].contiguous())
+        return res
+
     def dense_plan(self) -> torch.Tensor:
         """The dense schedule's plan built from the depth prior: (B*H, stride) int32, row = [n_windows, first sample offset of each
         window, the row's sample total]; plus L = 33 - S_max (the fixed-cut window length) as `.window` attribute.  See
@@ -380,7 +404,7 @@ class HotPathEngine:
         """The schedule argument of a render call: this engine's schedule, plus the plan-is-current flag while the depth prior
         the last prepare() consumed is untouched."""
         ready = self._plan_key is not None and self._prior_key(self._keep.get("depth_range")) == self._plan_key
-        return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0)
+        return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0) | (_lib.SCHED_PYR16_READY if self._pyr16_ready else 0)
 
     @property
     def n_bundles(self) -> int:

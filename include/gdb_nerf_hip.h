@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 4
+#define GDB_ABI_VERSION 5
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -143,6 +143,23 @@ int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_
                     size_t workspace_bytes, void* stream);
 
 /* ---- operator mirrors (one per reference method) ------------------------------------ */
+/* gdb_prepare / gdb_prepare_fpn (d_fpn_feat may be NULL: the gdb_prepare form) with options.  ABI v5.
+ *   GDB_PREP_PYR16  also write the HALF-PRECISION copy of the feature pyramid, in the same launch, from the same registers: what a
+ *                   GDB_PREC_F16 render gathers its feature taps from (16 + 4 bytes per tap and lane instead of 16 + 16 + 8, two
+ *                   load instructions instead of three; values = the fp32 pyramid's, rounded to nearest half once, every mip level
+ *                   box-filtered in fp32 first).  Replaces nothing of the reference: nvdiffrast rebuilds its fp32 mip stack inside
+ *                   every texture() call (bundle_sampler.py:355-359); this is a second, narrower copy for the opt-in fast path.
+ *                   Pass GDB_SCHED_PYR16_READY to the render calls of this frame. */
+#define GDB_PREP_PYR16 1
+int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, void* d_workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Where the half-precision pyramid sits in the workspace (tests / callers that read it): out[0] = byte offset, out[1] = bytes per
+ * (batch, view), out[2] = mip levels beyond 0, out[3 + l] = byte offset of level l inside a (batch, view) block.  A level of hw
+ * texels is three planes: [0, 16 hw) 16 bytes per texel = halves of channels 0..3, 8..11; [16 hw, 32 hw) channels 4..7, 12..15;
+ * [32 hw, 40 hw) 8 bytes per texel = channels 16..19 (19 is padding). */
+int gdb_pyramid16_layout(const GdbConfig* cfg, const GdbFrame* shape, size_t out[7]);
+
 /* BundleSampler.build_rays, bundle_sampler.py:30-74.  Needs gdb_prepare on the same
  * workspace first.  Outputs: d_rays_d (B,Ho,Wo,3), d_uv (Ho,Wo,2), d_rays_o (B,3),
  * d_z_axis (B,3), d_tar_pixel_radius (B). */
@@ -241,6 +258,8 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
 #define GDB_SCHED_SEGMENT_WAVE 2
 #define GDB_SCHED_DENSE 3
 #define GDB_SCHED_PLAN_READY 0x100 /* flag: the dense plan in d_workspace was built by gdb_prepare from the current d_depth_range */
+#define GDB_SCHED_PYR16_READY 0x200 /* flag (GDB_PREC_F16): the half-precision pyramid in d_workspace was built by gdb_prepare_ex(GDB_PREP_PYR16)
+                                     * for this frame; without it a GDB_PREC_F16 render first converts the fp32 pyramid (a launch of its own) */
 int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const void* d_workspace,
                              const float* d_packed_weights, int32_t row_begin, int32_t row_end,
                              int32_t precision, int32_t schedule, float* d_bundle_feat, float* d_depth,

@@ -46,8 +46,9 @@ def test_workspace_bytes_and_errors(lib):
     n = C.c_size_t()
     assert lib.gdb_workspace_bytes(C.byref(_cfg()), C.byref(_shape()), C.byref(n)) == 0
     pyr = 3 * 20 * 4 * (256 * 320 + 128 * 160 + 64 * 80 + 32 * 40)
-    # camera block + pyramid + per-bundle counts / offsets (mirror) + dense plan + sample list (4 B per sample offset of a row)
-    assert pyr < n.value < pyr + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + 96 * 1024
+    # camera block + pyramid + its half-precision copy (GDB_PREC_F16's taps) + per-bundle counts / offsets (mirror) + dense plan +
+    # sample list (4 B per sample offset of a row)
+    assert pyr + pyr // 2 < n.value < pyr + pyr // 2 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + 96 * 1024
     # reference error: network.py:33-34 ValueError('`Bundle size` must be a power of 2.')
     with pytest.raises(ValueError, match="power of 2"):
         _lib.check(lib.gdb_workspace_bytes(C.byref(_cfg(bundle_size=3)), C.byref(_shape()), C.byref(n)))
@@ -126,7 +127,7 @@ int main(void) {
     GdbConfig c; GdbFrame f;
     if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
     for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
-    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 4) return 12;
+    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 5) return 12;
     memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
     c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
     if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */

@@ -115,6 +115,35 @@ def test_feature_pyramid_is_bit_exact(Ho, Wo, V, B, levels):
             assert np.array_equal(npy(got[l][bi]).view(np.uint32), w.view(np.uint32)), (bi, l)
 
 
+@pytest.mark.parametrize("Ho,Wo,V,B,levels", [(64, 80, 3, 1, 3), (96, 72, 2, 2, 3), (40, 104, 2, 1, 3), (512, 640, 3, 1, 3), (12, 12, 2, 2, 3),
+                                               (64, 80, 2, 1, 0)])
+def test_half_precision_pyramid_is_the_fp32_one_rounded_once(Ho, Wo, V, B, levels):
+    """The copy of the pyramid GDB_PREC_F16 gathers from (gdb_prepare_ex GDB_PREP_PYR16; include/gdb_nerf_hip.h): every level equals
+    the oracle's fp32 mip level rounded to nearest half ONCE (the box filter runs in fp32), bit for bit - written by k_prepare itself
+    for an engine whose precision is f16, and by the conversion launch an f16 render makes when prepare was not asked for it.
+    (12, 12): a 6x6 map whose 3x3 level 1 gives the (batch, view) blocks a stride that is not a multiple of 16 bytes."""
+    frame = synthetic.make_frame(Ho, Wo, V=V, B=B, seed=17)
+    want = [[oracle.build_mips(np.transpose(frame["img_feat"][bi], (0, 2, 3, 1)), levels)] for bi in range(B)]
+    eng = HotPathEngine(max_mipmap_level=levels)
+    eng.precision = 0
+    eng.load_weights(synthetic.make_nerf_weights(seed=1))
+    eng.prepare(dev_frame(frame))                      # k_prepare writes both pyramids
+    assert eng._pyr16_ready
+    a = eng.feature_pyramid16()
+    eng2 = engine_for(frame, synthetic.make_nerf_weights(seed=1), max_mipmap_level=levels)   # fp32 engine: no half-precision copy yet
+    assert not eng2._pyr16_ready
+    r16 = eng2.render(precision=0)[0].clone()          # ... the f16 render converts the fp32 pyramid itself
+    b = eng2.feature_pyramid16()
+    for bi in range(B):
+        w = want[bi][0]
+        assert len(a) == len(w) == len(b)
+        for l, wl in enumerate(w):
+            h16 = wl.astype(np.float16)
+            assert np.array_equal(npy(a[l][bi]).view(np.uint16), h16.view(np.uint16)), (bi, l, "k_prepare")
+            assert np.array_equal(npy(b[l][bi]).view(np.uint16), h16.view(np.uint16)), (bi, l, "k_pyr16")
+    assert torch.equal(eng.render()[0], r16)           # both routes render the same image, bit for bit
+
+
 @pytest.mark.parametrize("tag", ["dtu", "nerfinv", "mips"])
 def test_encode_vs_golden(tag):
     """Inputs are the reference's own sample arrays; outputs against the reference's encode."""
