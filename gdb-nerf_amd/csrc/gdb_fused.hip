@@ -351,6 +351,25 @@ __device__ __forceinline__ void store_own16(float* rec, int col, int h, F val) {
     for (int i = 6; i < 15; ++i) rb[(12 + i - 6) * COMP_LD] = val(i);
     if (h == 0) rb[(12 + 9) * COMP_LD] = val(15);  // half 1's register 15 carries no channel
 }
+// ---- the output record of the one-wave schedules (segment wave, dense): BUNDLE-major, exactly as the rows lie in memory ----------
+// rec[col * ld + channel], ld = floats per output row (NOUT, or NOUT + 2 = [feat | depth | opacity] for the packed layout), so that
+// the window's output is one LINEAR copy LDS -> global, 16 bytes per lane and step with no index arithmetic.  (Round 3 kept the
+// record channel-major and every output element paid a division by 39 / 41 and a transposed LDS address: ~12 VALU instructions
+// per element, 20 elements per lane - 7 % of the wave's vector instructions, read off the ISA.)  ld is odd: lanes = columns
+// write conflict-free.  Three-tensor form: depth and opacity sit behind the 32 rows, [32 ld + col] and [32 ld + 32 + col].
+template <class F>
+__device__ __forceinline__ void out_store_own16(float* rec, int ld, int col, int h, F val) {
+    float* r = rec + col * ld;
+    float* ra = r + 2 * h;    // colours: channel c b^2 + 2h + e
+    float* rb = r + 10 * h;   // feat (+) rgb: channel 12 + 10h + (i - 6)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ra[(i >> 1) * 4 + (i & 1)] = val(i);
+#pragma unroll
+    for (int i = 6; i < 15; ++i) rb[12 + i - 6] = val(i);
+    if (h == 0) rb[12 + 9] = val(15);  // half 1's register 15 carries no channel
+}
+__device__ __forceinline__ float* out_depth_slot(float* rec, int ld, int col) { return ld == NOUT ? rec + 32 * NOUT + col : rec + col * ld + NOUT; }
+__device__ __forceinline__ float* out_opac_slot(float* rec, int ld, int col) { return ld == NOUT ? rec + 32 * NOUT + 32 + col : rec + col * ld + NOUT + 1; }
 // This lane's 16 staged values of one view in that order (what the softmax blend of nerf.py:110 accumulates)
 template <int PREC>
 __device__ __forceinline__ void load_blend16(const float* __restrict__ st, int j, int h, float val[16]) {
@@ -388,6 +407,28 @@ struct FusedArgs {
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     unsigned* dbg;    // diagnostic build only
 };
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte store to a 4-byte aligned address (gfx950: dword alignment suffices)
+// nb rows of the record -> bf[b0 ...] (and depth / opac in the three-tensor form); the whole wave calls it
+__device__ __forceinline__ void out_copy(const FusedArgs& a, const float* rec, size_t b0, int nb, int lane) {
+    const int ld = a.ldo, n = nb * ld, nv = n >> 2;
+    float* dst = a.bf + b0 * (size_t)ld;   // wave-uniform base; per-lane 32-bit offsets below
+#ifdef GDB_XP_SCALAROUT
+    (void)nv;
+    for (int i = lane; i < n; i += 64) *(float*)((char*)dst + 4u * (unsigned)i) = rec[i];
+#else
+    for (int i = lane; i < nv; i += 64)
+        *(f4u*)((char*)dst + 16u * (unsigned)i) = *(const f4u*)(rec + 4 * i);
+    if (lane < (n & 3)) dst[4 * nv + lane] = rec[4 * nv + lane];
+#endif
+    if (ld == NOUT) {
+        const int j = lane & 31;
+        if (j < nb) {
+            if (lane >> 5) a.opac[b0 + j] = rec[32 * NOUT + 32 + j];
+            else a.depth[b0 + j] = rec[32 * NOUT + j];
+        }
+    }
+}
+
 // The product library keeps NO process-global mutable state: schedule and precision are arguments of
 // the entry point.  Only the diagnostic build (-DGDB_DIAG: tools/stamps.py, tools/valu_split.sh) has a debug buffer and
 // reads GDB_FUSED_SKIP from the environment.
@@ -1272,6 +1313,23 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         // instructions per value and view like the plain sum / sum of squares (view 0 is the shift and adds nothing; the others pay
         // one subtraction), Welford's update four - but the cancellation is relative to the SPREAD of g over the views, not to its
         // magnitude (unnormalised FPN features of a real checkpoint; torch.var_mean is two-pass), and equal views give exactly 0.
+#ifdef GDB_XP_OLDVAR
+        float s1[12], s2[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const Tail32 tl = load_tail32<true>(stage + (size_t)v * STAGE_V, j, h);
+            float g[12];
+            view_g32(tl, q_view, b_view, g);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { s1[i] += g[i]; s2[i] = fmaf(g[i], g[i], s2[i]); }
+        }
+        const float rv = frcp((float)V), iv = frcp((float)(V - 1));
+        float mean[12], m2[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { mean[i] = s1[i] * rv; m2[i] = (s2[i] - s1[i] * mean[i]) * iv; }
+#else
         float g0[12], s1[12], s2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -1291,6 +1349,7 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         float mean[12], m2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { const float md = s1[i] * rv; mean[i] = g0[i] + md; m2[i] = (s2[i] - s1[i] * md) * iv; }
+#endif
         // mean channels 16..18 (half 0 of registers 8..10) move into half 1 of the variance registers 8..10, whose own
         // channels (20..22) do not exist: the mean chain then needs 8 steps instead of 12
         swap32_3(m2[8], mean[8], m2[9], mean[9], m2[10], mean[10]);
@@ -1689,35 +1748,21 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     const DevFrame& f = a.f;
     const float rden = 1.f / fmaxf(wsum, 1e-6f);
     __builtin_amdgcn_wave_barrier();
-    float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity
-    store_own16(o, j, h, [&](int i) { return oacc[i] * rden; });
+    float* o = stage;  // the output record: [32 bundles][ld] (+ depth, opacity behind it in the three-tensor form)
+    const int ld = a.ldo;
+    out_store_own16(o, ld, j, h, [&](int i) { return oacc[i] * rden; });
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + j] = of[i] * rden;
+    for (int i = 0; i < 4; ++i) o[j * ld + NBLEND + 4 * h + i] = of[i] * rden;
     if (h == 0) {
         const float d = dz * rden;
-        o[NOUT * COMP_LD + j] = f.inv_depth ? 1.f / d : d;  // network.py:88-89
-        o[(NOUT + 1) * COMP_LD + j] = wsum * rden;
+        *out_depth_slot(o, ld, j) = f.inv_depth ? 1.f / d : d;  // network.py:88-89
+        *out_opac_slot(o, ld, j) = wsum * rden;
     }
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     const int nvalid = min(32, f.W - seg * 32);
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)seg * 32;
-    if (a.ldo == NOUT) {
-        for (int qi = lane; qi < nvalid * NOUT; qi += 64) {
-            int jj = qi / NOUT, c = qi - jj * NOUT;
-            a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
-        }
-        if (j < nvalid) {
-            if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
-            else a.depth[b0 + j] = o[NOUT * COMP_LD + j];
-        }
-    } else {  // packed rows [feat | depth | opacity]
-        constexpr int LDO = NOUT + 2;
-        for (int qi = lane; qi < nvalid * LDO; qi += 64) {
-            int jj = qi / LDO, c = qi - jj * LDO;
-            a.bf[b0 * LDO + qi] = o[c * COMP_LD + jj];
-        }
-    }
+    out_copy(a, o, b0, nvalid, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1784,73 +1829,92 @@ __device__ __forceinline__ int dense_total(const DevFrame& f, int rlo, int rhi, 
     }
     return T;
 }
-// tile t -> (row, window); false past the last tile
-__device__ __forceinline__ bool dense_lookup(const DevFrame& f, int rlo, int rhi, int lane, int t, int& rowid, int& win) {
+// This wave's tiles - slot `slot` of XCD `xcd`: tiles xcd chunk + slot, + stride, ... inside the XCD's band [xcd chunk, (xcd + 1) chunk),
+// chunk = ceil(T / 8), at most 64 of them (the launcher sizes the grid so) - as descriptors row << 16 | window, one per LANE of a
+// single register: the scan of the per-row window counts runs once per wave, a tile of the walk then costs one v_readlane.
+// (Looked up per tile - a reload of the counts, a 6-step scan, a ballot - it was ~150 vector instructions per tile, 4 % of the
+// wave's, read off the ISA.)  Returns the number of descriptors written; rows are the global row index (< 65536, checked by the
+// launcher), windows < planMW <= 65535.
+__device__ __forceinline__ int dense_fill(const DevFrame& f, int rlo, int rhi, int lane, int xcd, int slot, int stride, unsigned& vdesc) {
     const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;
-    int run = 0;
-    for (int c0 = 0; c0 < nq; c0 += 64) {
-        int s4;
-        const int4 n = dense_counts(f, rlo, rhi, c0, lane, s4);
-        const int incl = wave_scan_incl(s4, lane);
-        const int tot = __shfl(incl, 63), tl = t - run;
-        if (tl < tot) {
+    int s4;
+    int4 n = dense_counts(f, rlo, rhi, 0, lane, s4);
+    int incl = wave_scan_incl(s4, lane);
+    // the total: this round's for strips of up to 256 rows (every BASELINE bundle map but c3 / c4 / c5), else one more pass over the counts
+    const int T = nq <= 64 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readfirstlane(dense_total(f, rlo, rhi, lane));
+    const int chunk = (T + 7) >> 3, t0 = xcd * chunk + slot, tend = min(T, (xcd + 1) * chunk);
+    int run = 0, i = 0;
+    vdesc = 0xFFFFFFFFu;
+    for (int c0 = 0; c0 < nq && i < 64; c0 += 64) {
+        if (c0) { n = dense_counts(f, rlo, rhi, c0, lane, s4); incl = wave_scan_incl(s4, lane); }
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        for (; i < 64; ++i) {   // this wave's tiles that fall into the rows of this round
+            const int t = t0 + i * stride;
+            if (t >= tend || t - run >= tot) break;
+            const int tl = t - run;
             const int ls = __builtin_ctzll(__ballot(tl < incl));  // the lane whose four rows hold the tile
             const int ex = __builtin_amdgcn_readlane(incl - s4, ls);
             const int nx = __builtin_amdgcn_readlane(n.x, ls), ny = __builtin_amdgcn_readlane(n.y, ls), nz = __builtin_amdgcn_readlane(n.z, ls);
             int r = (q0 + c0 + ls) << 2, rem = tl - ex;
             if (rem >= nx) { rem -= nx; ++r; if (rem >= ny) { rem -= ny; ++r; if (rem >= nz) { rem -= nz; ++r; } } }
-            rowid = r; win = rem;
-            return true;
+            if (lane == i) vdesc = ((unsigned)r << 16) | ((unsigned)rem & 0xFFFFu);   // (a v_cndmask on a wave-uniform value)
         }
+        if (t0 + i * stride >= tend) break;
         run += tot;
     }
-    return false;
+    return i;
 }
 
-template <int PREC, int WPS, int NWG>
+// PERSIST: the wave walks several tiles (the launch is the resident grid).  false: the grid has one wave per tile of the worst case
+// and a wave renders at most ONE tile - then nothing has to be kept out of the tile loop's way and the kernel arguments are plain
+// loop-free SGPR values again (the persistent form re-reads them through an opaque pointer in every tile: ~15 more scalar loads and
+// their waits per tile, 3 % of a tile at fp32).  The launcher takes the persistent form where the static walk wins (few tiles per
+// wave slot: c2) and this one elsewhere (c3 / c4: the hardware dispatcher balances uneven tiles better than a static stride).
+template <int PREC, int WPS, int NWG, bool PERSIST>
 __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     // Everything wave-uniform is re-derived inside each tile iteration from an opaque pointer to the kernel-argument segment (as in
     // k_render_solo): as loop invariants those values would be live across the whole body, which has no register to spare.
     typedef const FusedArgs __attribute__((address_space(4))) KArgs;
     KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    // ---- this wave's tiles: t0, t0 + stride, ... < tend ---------------------------------------------------------------------
+    // ---- this wave's tiles: t0, t0 + stride, ... < tend, looked up once (dense_fill) ---------------------------------------------
     // Rows are addressed by their global index (batch item x H + row), so one launch covers the rows [row_lo, row_hi) of ALL batch
-    // items and nothing but (t, tend) lives across a tile.
-    int t, tend;
+    // items, and nothing but the descriptor register and two counters lives across a tile.
+    unsigned vdesc;
+    int ntile;
     {
         const FusedArgs& a = *(const FusedArgs*)ap;
         const int lane = threadIdx.x & 63, wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-        const int T = __builtin_amdgcn_readfirstlane(dense_total(a.f, a.row_lo, a.row_hi, lane));
-        const int chunk = (T + 7) >> 3;                 // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2)
-        const int xcd = (int)(blockIdx.x & 7);
-        t = xcd * chunk + (int)(blockIdx.x >> 3) * NWG + wv;
-        tend = min(T, (xcd + 1) * chunk);
+        // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2); XCD x walks the band [x chunk, (x + 1) chunk) of the tiles
+        ntile = __builtin_amdgcn_readfirstlane(dense_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
+                                                          a.tile_stride, vdesc));
     }
-#ifdef GDB_DEBUG_STAMPS
-    int it = -1;
-#endif
-    while (t < tend) {
+    if (ntile <= 0) return;
+    int it = 0;
+    do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
     KArgs* apk = ap;
-    asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
-    const FusedArgs& a = *(const FusedArgs*)apk;
+    if constexpr (PERSIST) asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
+    // The arguments as VALUES: the by-value kernel parameter when the wave renders one tile (the compiler fetches it in a few wide
+    // scalar loads at kernel entry), a copy made at the top of every tile of the walk (one burst of scalar loads, through the opaque
+    // pointer so that nothing of it lives across tiles).  Read field by field through the pointer instead, each use paid a scalar
+    // load and its wait where it stood: +2.5 % on a tile (c3 fp32 180.5 -> 176.0 us, c4 211.7 -> 206.9: profiles/r04/ab_kernarg_access.txt).
+    const FusedArgs a_copy = *(const FusedArgs*)apk;
+    const FusedArgs& a = PERSIST ? a_copy : a_;
     const DevFrame& f = a.f;
-    const int tcur = t;
-    t += a.tile_stride;            // (the XCD's wave slots: set by the launcher)
     // ... and so is everything per-lane: nothing derived from the lane index may be hoisted out of the tile loop either
-    const int tid = opaque((int)threadIdx.x);
+    const int tid = PERSIST ? opaque((int)threadIdx.x) : (int)threadIdx.x;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
 #ifdef GDB_DEBUG_STAMPS  // one stamp record per (wave slot, tile iteration)
-    ++it;
     unsigned* dbg = a.dbg ? a.dbg + (size_t)it * gridDim.x * (16 * 16 * 2) : nullptr;
 #else
     unsigned* dbg = nullptr; (void)dbg;
 #endif
     // ---- dense tile index -> (row, window) -------------------------------------------------------------------------------
-    int rowid, win;
-    if (!dense_lookup(f, a.row_lo, a.row_hi, lane, tcur, rowid, win)) continue;
-    rowid = __builtin_amdgcn_readfirstlane(rowid); win = __builtin_amdgcn_readfirstlane(win);
+    const unsigned desc = (unsigned)__builtin_amdgcn_readlane((int)vdesc, it);
+    if (desc == 0xFFFFFFFFu) continue;
+    int rowid = (int)(desc >> 16), win = (int)(desc & 0xFFFFu);
+    if (rowid < a.row_lo || rowid >= a.row_hi) continue;
     const int bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? rowid / f.H : 0), row = rowid - bi * f.H;
     typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
     const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
@@ -1865,7 +1929,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     float tc[TAR_STRIDE];
     {
         const kfloat* tcg = kptr(tar_cam(f, bi));
-        asm volatile("" : "+s"(tcg));
+        if constexpr (PERSIST) asm volatile("" : "+s"(tcg));
 #pragma unroll
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
@@ -1880,6 +1944,9 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
     float vox[4];
+#ifdef GDB_XP_KEEPZ
+    float z_keep;
+#endif
     {
         float z_g;
         Bundle<4> q;
@@ -1887,6 +1954,9 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
         q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
+#ifdef GDB_XP_KEEPZ
+        z_keep = z_g;
+#endif
     }
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
@@ -1909,6 +1979,10 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     const int k = (int)((m_c >> 16) & 0xFFu), cnt = min(max((int)(m_c >> 24), 1), f.S_max);
     const int bj = min(max((int)(m_c & 0xFFFFu) - first, 0), nb - 1);
     float z;  // the sample's depth, derived again from the depth prior (two loads the gather has left in L1 / L2) as bundle_sample does
+#ifdef GDB_XP_KEEPZ
+    z = z_keep;
+    if (false)
+#endif
     {
         const size_t hw = (size_t)f.H * f.W;
         const unsigned pz = 4u * (unsigned)(row * f.W + first + bj);
@@ -1943,7 +2017,11 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
         for (int i = 0; i < 22; ++i) acc[i] = v[i];
         for (int d = 1; d < S; ++d) {
 #pragma unroll
+#ifdef GDB_XP_FMAHORNER
+            for (int i = 0; i < 22; ++i) acc[i] = fmaf(wave_shl1(acc[i]), has_next ? 1.f : 0.f, v[i]);
+#else
             for (int i = 0; i < 22; ++i) { const float nxv = wave_shl1(acc[i]); acc[i] = v[i] + (has_next ? nxv : 0.f); }
+#endif
         }
 #pragma unroll
         for (int i = 0; i < 22; ++i) v[i] = acc[i];
@@ -1970,41 +2048,27 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     STAMP(7);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
-    float* o = stage;  // [NOUT + 2][COMP_LD]: 39 channels, depth, opacity; column = bundle of the window
+    float* o = stage;  // the output record: [bundles of the window][ld] (+ depth, opacity behind it in the three-tensor form)
+    const int ld = a.ldo;
     if (act && k == 0) {
         const float rden = 1.f / fmaxf(v[20], 1e-6f);
-        store_own16(o, bj, h, [&](int i) { return v[i] * rden; });
+        out_store_own16(o, ld, bj, h, [&](int i) { return v[i] * rden; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[(NBLEND + 4 * h + i) * COMP_LD + bj] = v[16 + i] * rden;
+        for (int i = 0; i < 4; ++i) o[bj * ld + NBLEND + 4 * h + i] = v[16 + i] * rden;
         if (h == 0) {
             const float d = v[21] * rden;
-            o[NOUT * COMP_LD + bj] = f.inv_depth ? 1.f / d : d;  // network.py:88-89
-            o[(NOUT + 1) * COMP_LD + bj] = v[20] * rden;
+            *out_depth_slot(o, ld, bj) = f.inv_depth ? 1.f / d : d;  // network.py:88-89
+            *out_opac_slot(o, ld, bj) = v[20] * rden;
         }
     }
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)first;
-    if (a.ldo == NOUT) {
-        for (int qi = lane; qi < nb * NOUT; qi += 64) {
-            int jj = qi / NOUT, c = qi - jj * NOUT;
-            a.bf[b0 * NOUT + qi] = o[c * COMP_LD + jj];
-        }
-        if (j < nb) {
-            if (h) a.opac[b0 + j] = o[(NOUT + 1) * COMP_LD + j];
-            else a.depth[b0 + j] = o[NOUT * COMP_LD + j];
-        }
-    } else {  // packed rows [feat | depth | opacity]
-        constexpr int LDO = NOUT + 2;
-        for (int qi = lane; qi < nb * LDO; qi += 64) {
-            int jj = qi / LDO, c = qi - jj * LDO;
-            a.bf[b0 * LDO + qi] = o[c * COMP_LD + jj];
-        }
-    }
+    out_copy(a, o, b0, nb, lane);
     STAMP(8); STAMP(9);
     __builtin_amdgcn_wave_barrier();  // the next tile's gather overwrites the area the stores above read
     PHASE_FENCE();
-    }
+    } while (PERSIST && ++it < ntile);
 }
 
 // LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
@@ -2065,12 +2129,13 @@ static hipError_t resident_workgroups(K kernel, int threads, size_t lds, std::at
 
 template <int PREC, int WPS, int NWG>
 static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
-    static std::atomic<unsigned long long> done{0};
+    static std::atomic<unsigned long long> done{0}, done1{0};
     static std::atomic<unsigned long long> resident[64];
-    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG>, done);
+    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG, true>, done);
+    if (e == hipSuccess) e = allow_big_lds(k_render_dense<PREC, WPS, NWG, false>, done1);
     if (e != hipSuccess) return e;
     int per_cu = 1, cus = 1;
-    e = resident_workgroups(k_render_dense<PREC, WPS, NWG>, 64 * NWG, NWG * lds, resident, per_cu, cus);
+    e = resident_workgroups(k_render_dense<PREC, WPS, NWG, true>, 64 * NWG, NWG * lds, resident, per_cu, cus);
     if (e != hipSuccess) return e;
 #ifdef GDB_DIAG  // diagnostic build: over- / under-subscribe the persistent grid (workgroups per CU) from the environment
     static const int env_wgs = getenv("GDB_DENSE_WGS_PER_CU") ? atoi(getenv("GDB_DENSE_WGS_PER_CU")) : 0;
@@ -2088,10 +2153,24 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
         a.row_lo = (whole ? 0 : l * a.f.H) + a.row_begin;
         a.row_hi = whole ? (a.f.B - 1) * a.f.H + a.row_begin + a.nrows : a.row_lo + a.nrows;
         // never more workgroups than the worst case has tiles (every bundle at S_max)
-        const long long worst = (((long long)(a.row_hi - a.row_lo) * a.f.planMW + NWG - 1) / NWG + 7) / 8 * 8;
-        const long long g = grid > worst ? worst : grid;
+        const long long tiles = (long long)(a.row_hi - a.row_lo) * a.f.planMW;
+        const long long worst = ((tiles + NWG - 1) / NWG + 7) / 8 * 8;
+        long long g = grid > worst ? worst : grid;
+        // a wave keeps its tiles' descriptors in the 64 lanes of one register: at most 64 tiles per wave (8 XCD bands of ceil(tiles / 8))
+        const long long need = 8 * (((tiles + 7) / 8 + 64LL * NWG - 1) / (64LL * NWG));
+        if (g < need) g = need;
+        // Persistent walk or one tile per wave (measured on MI355X, profiles/r04/ab_persist_*.txt, same box, fp32 / f16 kernel us):
+        // c2 (2.7 worst-case tiles per wave slot) 103.4 vs 105.8 / 51.2 vs 52.7 for the walk; c3 (5.0) 184.6 vs 181.3 / 94.7 vs
+        // 92.9 against it: with many tiles per slot the dispatcher's dynamic order balances uneven tiles better than the stride.
+        bool persist = tiles <= 3 * grid * NWG;
+#ifdef GDB_DIAG
+        static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
+        if (env_persist >= 0) persist = env_persist != 0;
+#endif
+        if (!persist) g = worst;
         a.tile_stride = (int)(g >> 3) * NWG;
-        hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        if (persist) hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, true>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        else hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2104,7 +2183,7 @@ static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
     const size_t w1 = waves(1), w2 = waves(2), w4 = waves(4);
     a.wave_floats = (int)(lds / sizeof(float));
     const bool wide = GDB_DENSE_PREFER_WIDE != 0;
-    if (w4 > w2 && w4 > w1 || (wide && w4 >= w2 && w4 >= w1 && w4 > 0)) return launch_dense_n<PREC, WPS, 4>(a, lds, st);
+    if ((w4 > w2 && w4 > w1) || (wide && w4 >= w2 && w4 >= w1 && w4 > 0)) return launch_dense_n<PREC, WPS, 4>(a, lds, st);
     if (w2 > w1 || (wide && w2 >= w1 && w2 > 0)) return launch_dense_n<PREC, WPS, 2>(a, lds, st);
     return launch_dense_n<PREC, WPS, 1>(a, lds, st);
 }
@@ -2147,9 +2226,10 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     // 44 %).  Measured on MI355X (profiles/r03/schedules.txt), dense vs slot waves at f32: c2 103 vs 116 us, c3 183 vs 196,
     // c3' 215 vs 240; f16 / split-f16 on c2: 56.3 vs 56.5, 70.1 vs 71.0 (round 2's dense schedule lost on c2: its per-wave
     // count / scan / LDS-map prologue, a ds_bpermute composite, and a grid with dead workgroups between live ones).
-    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && fr->W < 65536);
+    const bool dense_fits = fr->W < 65536 && (long long)fr->B * fr->H < 65536;
+    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && dense_fits);
     if (want_dense && solo_lds <= lds_max) {
-        if (fr->W >= 65536) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles in 16 bits: W = %d >= 65536", fr->W);
+        if (!dense_fits) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
         // The plan + sample list are built here, into the plan region of the caller's workspace (a launch of its own on the same
         // stream), unless the caller vouches that gdb_prepare built them from the depth prior as it stands (GDB_SCHED_PLAN_READY).
         if (!plan_ready) {

@@ -20,6 +20,12 @@ def child(cases, steps):
             if not hasattr(probe, name):
                 del _lib._SIGNATURES[name]
         _lib.ABI_VERSION = probe.gdb_abi_version()
+        if not hasattr(probe, "gdb_prepare_ex"):   # ABI < 5: the engine's prepare call expressed in the older entry points
+            L = _lib.load()
+            L.gdb_prepare_ex = lambda cfg, f, fpn, flags, ws, n, st: (L.gdb_prepare_fpn(cfg, f, fpn, ws, n, st) if fpn else L.gdb_prepare(cfg, f, ws, n, st))
+            from gdb_nerf_amd import engine as _eng
+            _sched = _eng.HotPathEngine._sched
+            _eng.HotPathEngine._sched = lambda self: _sched(self) & ~_lib.SCHED_PYR16_READY   # (a flag those builds reject)
     from bench import WORKLOADS, PREC, to_dev
     from gdb_nerf_amd import synthetic
     from gdb_nerf_amd.engine import HotPathEngine

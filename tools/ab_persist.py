@@ -45,6 +45,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default="c2:f32")
     ap.add_argument("--wgs", default="0,2,4,5,6,7,64")
+    ap.add_argument("--persist", default="", help="comma list of GDB_DENSE_PERSIST values (1 = tile walk, 0 = one tile per wave) to run instead of --wgs: "
+                                                  "the launcher's two forms against each other, whatever its policy picks")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--child", action="store_true")
@@ -56,13 +58,13 @@ def main():
     from gdb_nerf_amd import build as _b
     lib = _b.build(tag="diag", extra=["-DGDB_DIAG"])
     res = {}
+    settings = [("persist " + v, {"GDB_DENSE_PERSIST": v}) for v in a.persist.split(",")] if a.persist else \
+               [(w, {"GDB_DENSE_WGS_PER_CU": w} if int(w) > 0 else {}) for w in a.wgs.split(",")]
     for rep in range(a.reps):
-        for w in a.wgs.split(","):
+        for w, extra in settings:
             env = dict(os.environ, GDB_NERF_LIB=lib)
-            if int(w) > 0:
-                env["GDB_DENSE_WGS_PER_CU"] = w
-            else:
-                env.pop("GDB_DENSE_WGS_PER_CU", None)
+            env.pop("GDB_DENSE_WGS_PER_CU", None); env.pop("GDB_DENSE_PERSIST", None)
+            env.update(extra)
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--case", a.case, "--steps", str(a.steps)],
                                env=env, capture_output=True, text=True, timeout=300)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
@@ -74,7 +76,7 @@ def main():
     print(f"case {a.case}: k_render_dense launch duration (us per render call, plan ready; events around {a.steps} calls) by workgroups per CU")
     for w, rs in res.items():
         us = [r["us"] for r in rs]
-        print(f"  wgs/CU {w:>3s}: " + " ".join(f"{u:7.2f}" for u in us) + f"   min {min(us):7.2f}   max|err| vs fp32 chain {max(r['err'] for r in rs):.2e}")
+        print(f"  {'wgs/CU ' if not a.persist else ''}{w:>3s}: " + " ".join(f"{u:7.2f}" for u in us) + f"   min {min(us):7.2f}   max|err| vs fp32 chain {max(r['err'] for r in rs):.2e}")
 
 
 if __name__ == "__main__":
