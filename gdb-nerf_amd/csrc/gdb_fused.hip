@@ -2159,10 +2159,13 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
         // a wave keeps its tiles' descriptors in the 64 lanes of one register: at most 64 tiles per wave (8 XCD bands of ceil(tiles / 8))
         const long long need = 8 * (((tiles + 7) / 8 + 64LL * NWG - 1) / (64LL * NWG));
         if (g < need) g = need;
-        // Persistent walk or one tile per wave (measured on MI355X, profiles/r04/ab_persist_*.txt, same box, fp32 / f16 kernel us):
-        // c2 (2.7 worst-case tiles per wave slot) 103.4 vs 105.8 / 51.2 vs 52.7 for the walk; c3 (5.0) 184.6 vs 181.3 / 94.7 vs
-        // 92.9 against it: with many tiles per slot the dispatcher's dynamic order balances uneven tiles better than the stride.
-        bool persist = tiles <= 3 * grid * NWG;
+        // Tile walk or one tile per wave: both forms are exact, the choice is speed only.  Measured on one MI355X, same process order
+        // (profiles/r04/ab_walk_vs_one_tile.txt; kernel us, walk / one tile per wave): c2 fp32 99.8 / 102.9, f16 50.8 / 52.4; c4 (S_max
+        // 6) fp32 202.9 / 206.0, f16 105.2 / 112.2, split-f16 140.0 / 146.3; but c3 fp32 181.6 / 175.7, f16 94.6 / 92.3; c3' fp32
+        // 216.6 / 209.8.  The walk saves the dispatcher's gap between two tiles of a wave slot; the dispatcher's dynamic order balances
+        // the long S_max 3 frames better than a static stride.  Rule fitted to those rows: the walk while the worst case is at most
+        // three tiles per resident wave, or when S_max > 4.
+        bool persist = tiles <= 3 * grid * NWG || a.f.S_max > 4;
 #ifdef GDB_DIAG
         static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
         if (env_persist >= 0) persist = env_persist != 0;
