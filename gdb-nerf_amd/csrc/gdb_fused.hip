@@ -1704,6 +1704,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     for (int k = 0; k < S; ++k) {
         KArgs* apk = ap;
         asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
+        // (a by-value copy per slot, as k_render_dense makes per tile, LOSES here: c5 f16 926 -> 970 us - this kernel has no register to spare)
         const FusedArgs& a = *(const FusedArgs*)apk;
         const DevFrame& f = a.f;
         unsigned* dbg = a.dbg; (void)dbg;
