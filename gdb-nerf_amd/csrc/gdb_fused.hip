@@ -412,14 +412,9 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte
 __device__ __forceinline__ void out_copy(const FusedArgs& a, const float* rec, size_t b0, int nb, int lane) {
     const int ld = a.ldo, n = nb * ld, nv = n >> 2;
     float* dst = a.bf + b0 * (size_t)ld;   // wave-uniform base; per-lane 32-bit offsets below
-#ifdef GDB_XP_SCALAROUT
-    (void)nv;
-    for (int i = lane; i < n; i += 64) *(float*)((char*)dst + 4u * (unsigned)i) = rec[i];
-#else
     for (int i = lane; i < nv; i += 64)
         *(f4u*)((char*)dst + 16u * (unsigned)i) = *(const f4u*)(rec + 4 * i);
     if (lane < (n & 3)) dst[4 * nv + lane] = rec[4 * nv + lane];
-#endif
     if (ld == NOUT) {
         const int j = lane & 31;
         if (j < nb) {
@@ -762,13 +757,17 @@ __device__ __forceinline__ f32x16 view_g(const Tail<X>& t, const Frag<X>& a_view
 // pose td == sd, and the reference's td - sd is exactly 0 (so the code is 0,0,0,1); a fused
 // fma(dd_t, r_t, -dd_s * r_s) would leave the product's rounding error instead, which the normalisation
 // then blows up to a unit vector of noise.
-__device__ __forceinline__ void view_dir_code(const float ctr[3], const float* __restrict__ to, const float* __restrict__ so,
-                                              float dir[4]) {
+// (td, the unit direction from the target camera to the sample, is the same for every view: target_dir(), once per sample)
+__device__ __forceinline__ void target_dir(const float ctr[3], const float* __restrict__ to, float td[3]) {
 #pragma clang fp contract(off)
-    float td[3], sd[3], dd[3], dif[3], dnn[3];
+    float dd[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - to[r];
     fnormalize3(dd, td);
+}
+__device__ __forceinline__ void view_dir_code(const float ctr[3], const float td[3], const float* __restrict__ so, float dir[4]) {
+#pragma clang fp contract(off)
+    float sd[3], dd[3], dif[3], dnn[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) dd[r] = ctr[r] - so[r];
     fnormalize3(dd, sd);
@@ -783,7 +782,7 @@ __device__ __forceinline__ void view_dir_code(const float ctr[3], const float* _
 // P16: the feature taps come from the half-precision pyramid (GDB_PREC_F16).
 template <bool P16>
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
-                                            float ball, const float* __restrict__ tc, float4 feat[3], float dir[4], float rgb[2][3], int skip) {
+                                            float ball, const float td[3], float4 feat[3], float dir[4], float rgb[2][3], int skip) {
     float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: scalar loads (of the entries used below), the block lives in SGPRs
     {
         const kfloat* scg = kptr(src_cam(f, bi, v));
@@ -858,7 +857,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
     else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
     if (two) { if constexpr (P16) taps_acc16<false>(t1, d1, feat); else taps_acc<false>(t1, d1, feat); }
-    view_dir_code(ctr, tc + T_O, sc + S_C, dir);
+    view_dir_code(ctr, td, sc + S_C, dir);
 }
 
 // Everything the views contribute to sample slot k of this wave's 32 bundles goes to LDS; returns
@@ -917,13 +916,15 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
 #pragma unroll
         for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
 
+    float td[3];
+    target_dir(ctr, tc + T_O, td);
     for (int v = 0; v < V; ++v) {
         float* st = stage + (size_t)v * stage_v<PREC>();
         // gather_view defines all 22 outputs; lanes without a sample in this slot stage unspecified values (never zeroed:
         // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
         float dir[4], rgb[2][3];
-        if (act) gather_view<PREC == GDB_PREC_F16>(f, bi, v, h, xyzh, ctr, ball, tc, feat, dir, rgb, skip);
+        if (act) gather_view<PREC == GDB_PREC_F16>(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
         else {
             const float u = __builtin_nondeterministic_value(0.f);
             feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
@@ -1313,23 +1314,6 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         // instructions per value and view like the plain sum / sum of squares (view 0 is the shift and adds nothing; the others pay
         // one subtraction), Welford's update four - but the cancellation is relative to the SPREAD of g over the views, not to its
         // magnitude (unnormalised FPN features of a real checkpoint; torch.var_mean is two-pass), and equal views give exactly 0.
-#ifdef GDB_XP_OLDVAR
-        float s1[12], s2[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-#pragma unroll 1
-        for (int v = 0; v < V; ++v) {
-            const Tail32 tl = load_tail32<true>(stage + (size_t)v * STAGE_V, j, h);
-            float g[12];
-            view_g32(tl, q_view, b_view, g);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { s1[i] += g[i]; s2[i] = fmaf(g[i], g[i], s2[i]); }
-        }
-        const float rv = frcp((float)V), iv = frcp((float)(V - 1));
-        float mean[12], m2[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { mean[i] = s1[i] * rv; m2[i] = (s2[i] - s1[i] * mean[i]) * iv; }
-#else
         float g0[12], s1[12], s2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -1349,7 +1333,6 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         float mean[12], m2[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) { const float md = s1[i] * rv; mean[i] = g0[i] + md; m2[i] = (s2[i] - s1[i] * md) * iv; }
-#endif
         // mean channels 16..18 (half 0 of registers 8..10) move into half 1 of the variance registers 8..10, whose own
         // channels (20..22) do not exist: the mean chain then needs 8 steps instead of 12
         swap32_3(m2[8], mean[8], m2[9], mean[9], m2[10], mean[10]);
@@ -1945,9 +1928,6 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
     float vox[4];
-#ifdef GDB_XP_KEEPZ
-    float z_keep;
-#endif
     {
         float z_g;
         Bundle<4> q;
@@ -1955,9 +1935,6 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
         q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
-#ifdef GDB_XP_KEEPZ
-        z_keep = z_g;
-#endif
     }
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
@@ -1980,10 +1957,6 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     const int k = (int)((m_c >> 16) & 0xFFu), cnt = min(max((int)(m_c >> 24), 1), f.S_max);
     const int bj = min(max((int)(m_c & 0xFFFFu) - first, 0), nb - 1);
     float z;  // the sample's depth, derived again from the depth prior (two loads the gather has left in L1 / L2) as bundle_sample does
-#ifdef GDB_XP_KEEPZ
-    z = z_keep;
-    if (false)
-#endif
     {
         const size_t hw = (size_t)f.H * f.W;
         const unsigned pz = 4u * (unsigned)(row * f.W + first + bj);
@@ -2012,17 +1985,16 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
         // Segmented suffix sums as a Horner chain: acc <- v + (the bundle has a next sample ? acc of the next lane : 0); after
         // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.  The neighbour is masked with a SELECT, not a
         // multiply by 0: a non-finite sum of the next bundle must stay in its own bundle (as in the other schedules and the reference).
-        const bool has_next = act && k + 1 < cnt;
+        // (The select sits on the SOURCE lane - "I continue the bundle of the lane below" - so that the shift folds into the add:
+        // v_cndmask + v_add_f32_dpp, two instructions per value and step; profiles/r04/ab_single_changes_f32.txt has the earlier forms.)
+        const bool is_cont = act && k > 0;   // this lane continues the bundle of the lane below it
         float acc[22];
 #pragma unroll
         for (int i = 0; i < 22; ++i) acc[i] = v[i];
         for (int d = 1; d < S; ++d) {
 #pragma unroll
-#ifdef GDB_XP_FMAHORNER
-            for (int i = 0; i < 22; ++i) acc[i] = fmaf(wave_shl1(acc[i]), has_next ? 1.f : 0.f, v[i]);
-#else
-            for (int i = 0; i < 22; ++i) { const float nxv = wave_shl1(acc[i]); acc[i] = v[i] + (has_next ? nxv : 0.f); }
-#endif
+            // mask at the SOURCE lane (a continuation lane: active, slot > 0), then one DPP add per value: acc <- v + shl(masked acc)
+            for (int i = 0; i < 22; ++i) { const float mk = is_cont ? acc[i] : 0.f; acc[i] = v[i] + wave_shl1(mk); }
         }
 #pragma unroll
         for (int i = 0; i < 22; ++i) v[i] = acc[i];
