@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--smax", type=int, default=0, help="override the workload's S_max (SURVEY §8(a): sweep 3, 6, 8; 0 = the workload's own)")
     ap.add_argument("--sampling", default="config", choices=["config", "adaptive", "fixed"], help="override the workload's sampling mode")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"], help="arithmetic of the NeRF MLP in the fused kernel")
-    ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense")
+    ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3, 4], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense, 4 flat")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
     ap.add_argument("--frame-ring", type=int, default=0,
@@ -536,8 +536,11 @@ def main():
     ab = alg_bytes(Ho, Wo, V) * share
     af = alg_flops(n_samples, V) * share
     if args.path == "fused":
-        auto = 3 if wl["adaptive"] else (1 if wl["S"] <= 3 else 2)   # GDB_SCHED_AUTO's rule (gdb_fused.hip render_launch)
-        kname = {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense"}[args.schedule or auto]
+        # GDB_SCHED_AUTO's rule (gdb_fused.hip render_launch): adaptive -> flat at fp32 for S_max <= 4 while the worst case is <= 3 tiles
+        # per wave slot, else dense; fixed counts -> slot waves (S_max <= 3) or segment wave
+        flat = args.precision == "f32" and wl["S"] <= 4 and (H * W * wl["S"] + 31) // 32 + 1 <= 3 * 3072
+        auto = (4 if flat else 3) if wl["adaptive"] else (1 if wl["S"] <= 3 else 2)
+        kname = {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[args.schedule or auto]
     else:
         kname = "k_mlp"
         ab = 4.0 * n_samples * (V * eng.P + 8 + 1 + eng.Q) + 4 * 11930  # what that kernel must read + write
@@ -633,9 +636,9 @@ def main():
             km8 = ev_ms(pairs8)
             ns8 = int(e8.sample()["total"].item())
             af8 = alg_flops(ns8, V)
-            sched8 = args.schedule or (3 if adaptive else (1 if smax <= 3 else 2))
+            sched8 = args.schedule or (3 if adaptive else (1 if smax <= 3 else 2))   # (S_max 8: never the flat schedule under AUTO)
             return {"S_max": smax, "sampling": "adaptive" if adaptive else "fixed", "precision": args.precision,
-                    "kernel": {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense"}[sched8],
+                    "kernel": {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[sched8],
                     "value": Ho * Wo * k2 / dt8, "ms_per_step": dt8 / k2 * 1e3, "steps": k2, "kernel_ms": km8, "n_samples": ns8,
                     "hbm_frac": ab / (km8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "mfma_frac": af8 / (km8 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[pname]}
         if args.workload == "c2" and not args.smax:

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
 ABI_VERSION = 5
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
-SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE = 0, 1, 2, 3
+SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE, SCHED_FLAT = 0, 1, 2, 3, 4
 SCHED_PLAN_READY = 0x100
 SCHED_PYR16_READY = 0x200
 PREP_PYR16 = 1

@@ -404,6 +404,8 @@ struct FusedArgs {
     int ldo;          // floats per output row of bf: NOUT, or NOUT + 2 for the packed layout [feat | depth | opacity]
     int wave_floats;  // dense schedule: floats of LDS per wave (a workgroup may hold two waves, each with its own area)
     int row_lo, row_hi, tile_stride;  // dense schedule: global rows (batch item x H + row) of this launch; tiles a wave skips per step
+    int flat_base;    // flat schedule: index of this launch's first window boundary in the side buffers (one launch per batch item)
+    int flat_last;    // flat schedule: the launch's last boundary in the worst case (every bundle at S_max): what k_flat_fix is launched for
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     unsigned* dbg;    // diagnostic build only
 };
@@ -2044,6 +2046,337 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     } while (PERSIST && ++it < ntile);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Flat schedule (GDB_SCHED_FLAT): the rows' compacted sample lists read as ONE list - literally the reference's flat sample list
+// (bundle_sampler.py:182-189) - cut into windows of exactly 32 consecutive samples: every lane of every wave but the list's last
+// carries a sample (the window plan of the dense schedule keeps bundles whole: 92-96 % of the lanes).  c2: 6,112 tiles instead of
+// 6,631 - which also is at most TWO tiles per resident wave slot (3,072), where 6,631 left a third, nearly empty round that a lone
+// wave per SIMD crawled through.
+// The price: a window may begin or end INSIDE a bundle.  Such a bundle is composited by neither wave: both leave the per-sample
+// records of their part (20 pre-weight values per lane half, alpha, the depth term) in the workspace, keyed by the window
+// boundary, and k_flat_fix - a small launch behind the render - composites it with exactly the arithmetic of the in-wave composite
+// (same products, same order of sums), so that a bundle's result does not depend on where the windows fall: row strips of the
+// frame stay bit-identical to the full render.
+// A window may also span bundle-map rows (the row of a lane is per-lane; a row holds >= W samples, so two rows in all but tiny maps).
+// Tiles are looked up once per wave like the dense schedule's: descriptor = first row << 16 | sample offset inside that row.
+__device__ __forceinline__ int4 flat_counts(const DevFrame& f, int rlo, int rhi, int c0, int lane, int& s4) {
+    const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;
+    const int q = c0 + lane;
+    int4 n = make_int4(0, 0, 0, 0);
+    if (q < nq) n = ((const int4*)f.nsamp)[q0 + q];
+    const int r4 = (q0 + q) << 2, cap = f.smapStride - 32;   // (a row's list holds at most W S_max <= smapStride - 32 entries)
+    n.x = (r4 + 0 >= rlo && r4 + 0 < rhi) ? min(max(n.x, 0), cap) : 0;
+    n.y = (r4 + 1 >= rlo && r4 + 1 < rhi) ? min(max(n.y, 0), cap) : 0;
+    n.z = (r4 + 2 >= rlo && r4 + 2 < rhi) ? min(max(n.z, 0), cap) : 0;
+    n.w = (r4 + 3 >= rlo && r4 + 3 < rhi) ? min(max(n.w, 0), cap) : 0;
+    s4 = n.x + n.y + n.z + n.w;
+    return n;
+}
+// samples of the rows [rlo, rhi)
+__device__ __forceinline__ int flat_total(const DevFrame& f, int rlo, int rhi, int lane) {
+    const int nq = ((rhi + 3) >> 2) - (rlo >> 2);
+    int T = 0;
+    for (int c0 = 0; c0 < nq; c0 += 64) {
+        int s; flat_counts(f, rlo, rhi, c0, lane, s);
+        T += __shfl(wave_scan_incl(s, lane), 63);
+    }
+    return T;
+}
+// This wave's tiles (slot `slot` of XCD `xcd`, as dense_fill) -> descriptors, one per lane; T = tiles of the launch (out).
+__device__ __forceinline__ int flat_fill(const DevFrame& f, int rlo, int rhi, int lane, int xcd, int slot, int stride, unsigned& vdesc, int& t0_out, int& T_out) {
+    const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;
+    int s4;
+    int4 n = flat_counts(f, rlo, rhi, 0, lane, s4);
+    int incl = wave_scan_incl(s4, lane);
+    const int NS = nq <= 64 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readfirstlane(flat_total(f, rlo, rhi, lane));
+    const int T = (NS + 31) >> 5;
+    const int chunk = (T + 7) >> 3, t0 = xcd * chunk + slot, tend = min(T, (xcd + 1) * chunk);
+    t0_out = t0; T_out = T;
+    int run = 0, i = 0;
+    vdesc = 0xFFFFFFFFu;
+    for (int c0 = 0; c0 < nq && i < 64; c0 += 64) {
+        if (c0) { n = flat_counts(f, rlo, rhi, c0, lane, s4); incl = wave_scan_incl(s4, lane); }
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        for (; i < 64; ++i) {   // this wave's tiles whose FIRST sample falls into the rows of this round
+            const int t = t0 + i * stride;
+            if (t >= tend || 32 * t - run >= tot) break;
+            const int gl = 32 * t - run;                            // offset of the tile's first sample inside this round
+            const int ls = __builtin_ctzll(__ballot(gl < incl));   // the lane whose four rows hold it
+            const int ex = __builtin_amdgcn_readlane(incl - s4, ls);
+            const int nx = __builtin_amdgcn_readlane(n.x, ls), ny = __builtin_amdgcn_readlane(n.y, ls), nz = __builtin_amdgcn_readlane(n.z, ls);
+            int r = (q0 + c0 + ls) << 2, rem = gl - ex;
+            if (rem >= nx) { rem -= nx; ++r; if (rem >= ny) { rem -= ny; ++r; if (rem >= nz) { rem -= nz; ++r; } } }
+            if (lane == i) vdesc = ((unsigned)r << 16) | ((unsigned)rem & 0xFFFFu);
+        }
+        if (t0 + i * stride >= tend) break;
+        run += tot;
+    }
+    return i;
+}
+
+// the side record of sample slot k, lane half h, of the bundle straddling window boundary b
+__device__ __forceinline__ float* flat_rec(const DevFrame& f, int b, int k, int h) {
+    return f.side + ((size_t)((size_t)b * f.S_max + k) * 2 + h) * FLAT_REC;
+}
+
+template <int PREC, int WPS, int NWG, bool PERSIST>
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
+    typedef const FusedArgs __attribute__((address_space(4))) KArgs;
+    KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned vdesc;
+    int ntile, t0;
+    {
+        const FusedArgs& a = *(const FusedArgs*)ap;
+        const int lane = threadIdx.x & 63, wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+        int T;
+        ntile = __builtin_amdgcn_readfirstlane(flat_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
+                                                         a.tile_stride, vdesc, t0, T));
+        t0 = __builtin_amdgcn_readfirstlane(t0);
+        // k_flat_fix is launched for the worst-case number of boundaries: those behind the list's end (never written by a tile) are
+        // marked empty here, a few per wave.  (The "header" of a boundary - which bundle straddles it, how many samples it has - rides
+        // in the two padding floats of the slot-0 records: the fix-up fetches everything of a boundary in ONE memory round trip.)
+        {
+            const int nw = (int)gridDim.x * NWG, me = (int)blockIdx.x * NWG + wv;
+            for (int b = T + 1 + me * 64 + lane; b <= a.flat_last; b += nw * 64) {
+                ((int*)flat_rec(a.f, a.flat_base + b, 0, 0))[22] = -1; ((int*)flat_rec(a.f, a.flat_base + b, 0, 1))[22] = -1;
+            }
+        }
+    }
+    if (ntile <= 0) return;
+    int it = 0;
+    do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
+    KArgs* apk = ap;
+    if constexpr (PERSIST) asm volatile("" : "+s"(apk));
+    const FusedArgs a_copy = *(const FusedArgs*)apk;   // the arguments as values (see k_render_dense)
+    const FusedArgs& a = PERSIST ? a_copy : a_;
+    const DevFrame& f = a.f;
+    const int tid = PERSIST ? opaque((int)threadIdx.x) : (int)threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
+    unsigned* dbg = nullptr; (void)dbg;
+    // ---- tile -> (first row, offset in that row); the rows the window covers ------------------------------------------------
+    const unsigned desc = (unsigned)__builtin_amdgcn_readlane((int)vdesc, it);
+    if (desc == 0xFFFFFFFFu) continue;
+    const int tile = t0 + it * a.tile_stride;        // this tile's index in the launch = the boundary behind it
+    const int r0 = (int)(desc >> 16), off0 = (int)(desc & 0xFFFFu);
+    if (r0 < a.row_lo || r0 >= a.row_hi) continue;
+    const int bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? r0 / f.H : 0);   // (one launch per batch item: every row of the window is its)
+    typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
+    const kint* kns = (const kint*)f.nsamp;
+    int cov = 0, my_row = r0, my_ent = 0;
+    bool have = false;
+    {
+        int rr = r0, eoff = off0;
+        while (cov < 32 && rr < a.row_hi) {   // (one or two rows in all but tiny maps)
+            const int ns = min(max(kns[rr], 0), f.smapStride - 32);
+            const int take = min(max(ns - eoff, 0), 32 - cov);
+            if (j >= cov && j < cov + take) { my_row = rr; my_ent = eoff + (j - cov); have = true; }
+            cov += take; ++rr; eoff = 0;
+        }
+    }
+    const int n = cov;
+    if (n <= 0) continue;
+    unsigned m = 0xFFFFFFFFu;
+    if (have) m = ldu<unsigned>(f.smap, 4u * (unsigned)(my_row * f.smapStride + my_ent));
+    float tc[TAR_STRIDE];
+    {
+        const kfloat* tcg = kptr(tar_cam(f, bi));
+        if constexpr (PERSIST) asm volatile("" : "+s"(tcg));
+#pragma unroll
+        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
+    }
+    const int mx = min((int)(m & 0xFFFFu), f.W - 1), k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
+    const int row_l = my_row - bi * f.H;             // this lane's bundle-map row inside its batch item
+    const int gbl = row_l * f.W + mx;                // ... and its bundle index inside the batch item's map (< 2^24, checked by the launcher)
+    // the window's bundles: lane 0's .. the last lane's; bundles hold >= 1 sample each, so they are consecutive map indices, <= 32
+    const int first = __builtin_amdgcn_readfirstlane(gbl);
+    const int nb = min(max(__builtin_amdgcn_readlane(gbl, n - 1) - first + 1, 0), 32);
+    if (nb <= 0 || first < 0 || first + nb > f.H * f.W) continue;
+    const bool act = have && m != 0xFFFFFFFFu && gbl - first >= 0 && gbl - first < nb && k_g < mcnt && mcnt >= 1 && mcnt <= f.S_max;
+    // does the window begin / end inside a bundle?  (its first sample is not slot 0 / its last sample is not the bundle's last)
+    const int hp = __builtin_amdgcn_readfirstlane(k_g) > 0 ? 1 : 0;
+    const int tp = (__builtin_amdgcn_readlane(k_g, n - 1) + 1 < __builtin_amdgcn_readlane(mcnt, n - 1)) ? 1 : 0;
+    const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
+    const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
+    // what has to survive gather + MLP in ONE register: map index (24 bits) | slot (4) | count - 1 (4)
+    const unsigned m2 = (unsigned)gbl | ((unsigned)min(k_g, 15) << 24) | ((unsigned)(min(max(mcnt, 1), 16) - 1) << 28);
+    float vox[4];
+    {
+        float z_g;
+        Bundle<4> q;
+        load_bundle<4, true, false>(f, tc, bi, row_l, mx, q);
+        q.count = min(max(mcnt, 1), f.S_max);
+        slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
+    float sig;
+    {
+        float bacc[16], fhv[4];
+        if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+        else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = bacc[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[16 + i] = fhv[i];
+    }
+    // ---- composite across the lanes of a bundle (as k_render_dense) ---------------------------------------------------------
+    const unsigned m_c = (unsigned)opaque((int)m2);
+    const int gb = (int)(m_c & 0xFFFFFFu), k = (int)((m_c >> 24) & 0xFu), cnt = min((int)(m_c >> 28) + 1, f.S_max);
+    const int bj = min(max(gb - first, 0), nb - 1);
+    float z;
+    {
+        const size_t hw = (size_t)f.H * f.W;
+        const unsigned pz = 4u * (unsigned)gb;
+        float n0 = ldu<float>(f.depth_range + ((size_t)bi * 2) * hw, pz), f0 = ldu<float>(f.depth_range + ((size_t)bi * 2 + 1) * hw, pz);
+        if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
+        z = sample_mid<true>(n0, f0, cnt, min(k, cnt - 1));
+        if (f.inv_depth) z = gdiv<true>(1.f, z);
+    }
+    const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
+    const float zt = f.inv_depth ? 1.f / z : z;
+    // a straddling bundle's samples go to the side records of their boundary (the one before this tile for the window's first
+    // bundle, the one behind it for its last): k_flat_fix composites them
+    {
+        const bool in_head = hp && bj == 0, in_tail = tp && bj == nb - 1;
+        if (act && (in_head || in_tail)) {
+            float* r = flat_rec(f, a.flat_base + tile + (in_head ? 0 : 1), k, h);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ((float4*)r)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            ((float2*)r)[10] = make_float2(al, zt);
+            if (in_tail && k == 0) { ((int*)r)[22] = gb; ((int*)r)[23] = cnt; }   // the boundary's header: map index, sample count
+        }
+        if (!tp && j == 0) ((int*)flat_rec(f, a.flat_base + tile + 1, 0, h))[22] = -1;   // no bundle straddles the boundary behind this tile
+    }
+    const int S = f.S_max;
+    if (S <= 4) {
+        float Tr = 1.f, ap_ = al;
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            ap_ = wave_shr1(ap_);
+            if (d <= k) Tr *= 1.f - ap_;
+        }
+        const float w = al * Tr;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
+        v[20] = w;
+        v[21] = act ? w * zt : 0.f;
+        const bool is_cont = act && k > 0 && j > 0;   // (lane 32 = sample 0 of the other half: never a continuation of lane 31's bundle,
+                                                       // although its slot is > 0 when the window begins inside a bundle)
+        float acc[22];
+#pragma unroll
+        for (int i = 0; i < 22; ++i) acc[i] = v[i];
+        for (int d = 1; d < S; ++d) {
+#pragma unroll
+            for (int i = 0; i < 22; ++i) { const float mk = is_cont ? acc[i] : 0.f; acc[i] = v[i] + wave_shl1(mk); }
+        }
+#pragma unroll
+        for (int i = 0; i < 22; ++i) v[i] = acc[i];
+    } else {
+        float Tr = 1.f;
+        for (int d = 1; d < S; ++d) {
+            const float ap_ = __shfl_up(al, d, 32);
+            if (d <= k) Tr *= 1.f - ap_;
+        }
+        const float w = al * Tr;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
+        v[20] = w;
+        v[21] = act ? w * zt : 0.f;
+        for (int d = 1; d < S; d <<= 1) {
+            const bool take = act && k + d < cnt;
+#pragma unroll
+            for (int i = 0; i < 22; ++i) {
+                const float tt = __shfl_down(v[i], d, 32);
+                if (take) v[i] += tt;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    // the window's WHOLE bundles (columns hp .. nb - 1 - tp) to the output record, column 0 = the first whole one
+    float* o = stage;
+    const int ld = a.ldo, col = bj - hp, ncol = nb - hp - tp;
+    if (act && k == 0 && col >= 0 && col < ncol) {
+        const float rden = 1.f / fmaxf(v[20], 1e-6f);
+        out_store_own16(o, ld, col, h, [&](int i) { return v[i] * rden; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[col * ld + NBLEND + 4 * h + i] = v[16 + i] * rden;
+        if (h == 0) {
+            const float d = v[21] * rden;
+            *out_depth_slot(o, ld, col) = f.inv_depth ? 1.f / d : d;  // network.py:88-89
+            *out_opac_slot(o, ld, col) = v[20] * rden;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    if (ncol > 0) out_copy(a, o, (size_t)bi * f.H * f.W + (size_t)(first + hp), ncol, lane);
+    __builtin_amdgcn_wave_barrier();
+    PHASE_FENCE();
+    } while (PERSIST && ++it < ntile);
+}
+
+// The bundles that straddle a window boundary of the flat schedule, from the per-sample records both waves left: one wave per
+// boundary, lane (h, i) = lane half x value index (0..19 the weighted values, 20 the weight, 21 weight x depth term), EXACTLY the
+// in-wave composite's arithmetic: transmittance as the product over the earlier samples nearest first, weights alpha x T, the sums
+// right-nested (S_max <= 4: the Horner chain) or by doubling (S_max > 4: the ds_bpermute steps).
+// NS = slots unrolled (registers, all records requested up front: one memory round trip behind the header's): 4 for S_max <= 4, 16 else.
+template <int NS>
+__global__ void __launch_bounds__(256) k_flat_fix(FusedArgs a) {
+#pragma clang fp contract(off)
+    const DevFrame& f = a.f;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+    const int b = (int)blockIdx.x * 4 + wv + 1;           // boundary behind tile b - 1 (boundaries behind the list's end are marked empty)
+    if (b > a.flat_last) return;                           // (the grid's last workgroup may reach past the worst case)
+    const int S = f.S_max;
+    float val[NS], alv[NS], ztv[NS];
+    const float* r0 = flat_rec(f, a.flat_base + b, 0, h);
+    const int gb = ((const int*)r0)[22], cnt = ((const int*)r0)[23];   // the header rides in slot 0's padding (written by the tail side)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {   // every slot the config can have, unconditionally: ONE round trip (slots past the count are unused)
+        const float* r = r0 + (size_t)min(k, S - 1) * 2 * FLAT_REC;
+        alv[k] = r[20]; ztv[k] = r[21]; val[k] = r[i < 20 ? i : 0];
+    }
+    if (gb < 0 || cnt < 2 || cnt > S || cnt > NS || gb >= f.H * f.W) return;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        float Tr = 1.f;
+#pragma unroll
+        for (int d = 1; d <= k; ++d) if (S > 4 ? d < S : d < 4) Tr *= 1.f - alv[k - d];
+        const float w = alv[k] * Tr;
+        val[k] = i < 20 ? w * val[k] : (i == 20 ? w : w * ztv[k]);
+    }
+    float acc;
+    if (S <= 4) {
+        acc = 0.f;
+        bool started = false;
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k)
+            if (k < cnt) { acc = started ? val[k] + acc : val[k]; started = true; }
+    } else {
+#pragma unroll
+        for (int d = 1; d < NS; d <<= 1)
+            if (d < S) {
+#pragma unroll
+                for (int k = 0; k + d < NS; ++k) if (k + d < cnt) val[k] = val[k] + val[k + d];   // ascending k reads the not yet updated k + d
+            }
+        acc = val[0];
+    }
+    const float wsum = __shfl(acc, (h << 5) | 20), rden = 1.f / fmaxf(wsum, 1e-6f);
+    const size_t row = (size_t)(a.f.B > 1 ? a.row_lo / f.H : 0) * f.H * f.W + (size_t)gb;
+    int ch = -1;
+    if (i < 16) ch = own_chan(h, i);
+    else if (i < 20) ch = NBLEND + 4 * h + (i - 16);
+    if (ch >= 0) a.bf[row * a.ldo + ch] = acc * rden;
+    if (h == 0 && i == 20) { if (a.ldo == NOUT) a.opac[row] = acc * rden; else a.bf[row * a.ldo + NOUT + 1] = acc * rden; }
+    if (h == 0 && i == 21) {
+        const float d = acc * rden, dd = f.inv_depth ? 1.f / d : d;
+        if (a.ldo == NOUT) a.depth[row] = dd; else a.bf[row * a.ldo + NOUT] = dd;
+    }
+}
+
 // LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
 // function: the once-flag is a bit per device ordinal (relaxed atomics; setting it twice is harmless).
 #include <atomic>
@@ -2164,6 +2497,65 @@ static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
     return launch_dense_n<PREC, WPS, 1>(a, lds, st);
 }
 
+// Flat schedule: one launch of k_render_flat per batch item (a window never crosses batch items), then k_flat_fix for the bundles
+// that straddle a window boundary.  Grid and walk / one-tile rule as launch_dense_n.
+template <int PREC, int WPS, int NWG>
+static hipError_t launch_flat_n(FusedArgs& a, size_t lds, int max_tiles_per_item, hipStream_t st) {
+    // (the split-f16 build at three waves per SIMD has no register left for the walk's loop state: one tile per wave there)
+    constexpr bool CAN_WALK = !(PREC == GDB_PREC_F32X && WPS == 3);
+    static std::atomic<unsigned long long> done{0}, done1{0};
+    static std::atomic<unsigned long long> resident[64];
+    hipError_t e = allow_big_lds(k_render_flat<PREC, WPS, NWG, CAN_WALK>, done);
+    if (e == hipSuccess) e = allow_big_lds(k_render_flat<PREC, WPS, NWG, false>, done1);
+    if (e != hipSuccess) return e;
+    int per_cu = 1, cus = 1;
+    e = resident_workgroups(k_render_flat<PREC, WPS, NWG, CAN_WALK>, 64 * NWG, NWG * lds, resident, per_cu, cus);
+    if (e != hipSuccess) return e;
+#ifdef GDB_DIAG
+    static const int env_wgs = getenv("GDB_DENSE_WGS_PER_CU") ? atoi(getenv("GDB_DENSE_WGS_PER_CU")) : 0;
+    if (env_wgs > 0) per_cu = env_wgs;
+#endif
+    long long grid = (long long)per_cu * cus;
+    grid = grid >= 8 ? grid / 8 * 8 : 8;
+    for (int bi = 0; bi < a.f.B; ++bi) {
+        a.row_lo = bi * a.f.H + a.row_begin;
+        a.row_hi = a.row_lo + a.nrows;
+        a.flat_base = bi * (max_tiles_per_item + 1);
+        const long long tiles = ((long long)a.nrows * a.f.W * a.f.S_max + 31) / 32 + 1;   // worst case: every bundle at S_max
+        a.flat_last = (int)tiles;   // boundaries 1 .. tiles (boundary b sits behind tile b - 1); the workspace holds max_tiles_per_item + 1 >= tiles + 1 of them
+        const long long worst = ((tiles + NWG - 1) / NWG + 7) / 8 * 8;
+        long long g = grid > worst ? worst : grid;
+        const long long need = 8 * (((tiles + 7) / 8 + 64LL * NWG - 1) / (64LL * NWG));   // at most 64 tiles per wave (one descriptor per lane)
+        if (g < need) g = need;
+        bool persist = CAN_WALK && (tiles <= 3 * grid * NWG || a.f.S_max > 4);   // (launch_dense_n's rule)
+#ifdef GDB_DIAG
+        static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
+        if (env_persist >= 0) persist = CAN_WALK && env_persist != 0;
+#endif
+        if (!persist) g = worst;
+        a.tile_stride = (int)(g >> 3) * NWG;
+        if (persist) hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, CAN_WALK>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        else hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (a.f.S_max <= 4) hipLaunchKernelGGL(k_flat_fix<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_flat_fix<GDB_MAX_SAMPLES>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+template <int PREC, int WPS>
+static hipError_t launch_flat(FusedArgs& a, size_t lds, int max_tiles_per_item, hipStream_t st) {
+    const size_t gran = 1280, cap = 160 * 1024;
+    auto waves = [&](size_t n) { return n * lds > cap ? (size_t)0 : n * (cap / ((n * lds + gran - 1) / gran * gran)); };
+    const size_t w1 = waves(1), w2 = waves(2), w4 = waves(4);
+    a.wave_floats = (int)(lds / sizeof(float));
+    if (w4 > w2 && w4 > w1) return launch_flat_n<PREC, WPS, 4>(a, lds, max_tiles_per_item, st);
+    if (w2 > w1) return launch_flat_n<PREC, WPS, 2>(a, lds, max_tiles_per_item, st);
+    return launch_flat_n<PREC, WPS, 1>(a, lds, max_tiles_per_item, st);
+}
+
 template <bool LOOP, int WAVES, int PREC>
 static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
@@ -2203,6 +2595,33 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     // c3' 215 vs 240; f16 / split-f16 on c2: 56.3 vs 56.5, 70.1 vs 71.0 (round 2's dense schedule lost on c2: its per-wave
     // count / scan / LDS-map prologue, a ds_bpermute composite, and a grid with dead workgroups between live ones).
     const bool dense_fits = fr->W < 65536 && (long long)fr->B * fr->H < 65536;
+    // Flat: windows of 32 consecutive samples of the compacted list (bundles may straddle windows; k_flat_fix).  Its descriptors pack a
+    // row (16 bits) with a sample offset inside the row (16 bits), its lanes a map index (24 bits) with slot and count (4 + 4 bits),
+    // and the sample list is addressed with one 32-bit byte offset.
+    const bool flat_fits = dense_fits && (long long)fr->W * S < 65536 && (long long)fr->H * fr->W < (1 << 24) && S <= 16 &&
+                           (unsigned long long)fr->B * fr->H * (unsigned long long)(a.f.smapStride) * 4ull < (1ull << 32);
+    // GDB_SCHED_AUTO takes it where it measured faster than the window plan (profiles/r04/ab_dense_vs_flat.txt, same box, kernel us
+    // incl. the 5 us fix-up launch): fp32 on frames of few tiles per wave slot with S_max <= 4 - c2: 96.5 vs 99.8 (8 % fewer tiles:
+    // 6,112 instead of 6,631).  Not at f16 / split-f16 (a tile is half as long, the fix-up launch weighs twice: c2 f16 54.0 vs 50.9),
+    // not on c3 / c4 (greedy windows already fill 96 % of the lanes: 182.5 vs 176.0, 227.8 vs 204.2).
+    const bool flat_wins = PREC == GDB_PREC_F32 && S <= 4 &&
+                           ((long long)a.nrows * fr->W * S + 31) / 32 + 1 <= 3LL * 3072;   // (worst case <= 3 tiles per wave slot of a 256-CU part)
+    const bool want_flat = sched == GDB_SCHED_FLAT || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && flat_fits && flat_wins);
+    if (want_flat && solo_lds <= lds_max) {
+        if (!flat_fits) return gdb_fail(GDB_E_SHAPE, "the flat schedule needs W x S_max < 65536, B x H < 65536, H x W < 2^24 (W = %d, H = %d, B = %d, S_max = %d)", fr->W, fr->H, fr->B, S);
+        if (!plan_ready) {
+            int rc = gdb_build_dense_plan(cfg, fr, const_cast<void*>(ws), st);
+            if (rc) return rc;
+        }
+        a.alias = 0;
+        const int max_tiles = (int)(((long long)fr->H * fr->W * S + 31) / 32 + 1);
+        bool three = false;
+        if constexpr (PREC != GDB_PREC_F32) three = waves_by_lds(solo_lds + pad) > 8 || 2 * waves_by_lds(2 * (solo_lds + pad)) > 8;
+        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_flat<PREC, 3>(a, (solo_lds + pad + 15) / 16 * 16, max_tiles, st); }
+        if (!three) e = launch_flat<PREC, 2>(a, (solo_lds + pad + 15) / 16 * 16, max_tiles, st);
+        if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_flat: %s", hipGetErrorString(e));
+        return GDB_OK;
+    }
     const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && dense_fits);
     if (want_dense && solo_lds <= lds_max) {
         if (!dense_fits) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
@@ -2255,7 +2674,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
         return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA, 2 = split-f16 operands)", precision);
     const bool plan_ready = (schedule & GDB_SCHED_PLAN_READY) != 0, pyr16_ready = (schedule & GDB_SCHED_PYR16_READY) != 0;
     schedule &= ~(GDB_SCHED_PLAN_READY | GDB_SCHED_PYR16_READY);
-    if (schedule < 0 || schedule > 3) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..3", schedule);
+    if (schedule < 0 || schedule > 4) return gdb_fail(GDB_E_BADARG, "schedule %d outside 0..4", schedule);
     // the reference's unbiased variance over views (nerf.py:73) is NaN for a single view
     if (fr->V < 2) return gdb_fail(GDB_E_SHAPE, "fused kernel needs at least 2 source views (got %d)", fr->V);
     if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
@@ -2275,7 +2694,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
-    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1;
+    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1; a.flat_base = 0; a.flat_last = 0;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     a.skip = env_skip; a.dbg = g_dbg;

@@ -74,6 +74,9 @@ struct WsLayout {
     int smapStride;     // entries per bundle-map row (planMW * planL + 32: a window's 32 lanes never read past it)
     size_t nwinOff;     // dense schedule: windows in use per bundle-map row (int32 per row, padded to whole int4s): the render waves
                         // turn a dense tile index into (row, window) with one scan of it, so the grid holds no empty windows between rows
+    size_t nsampOff;    // flat schedule: samples per bundle-map row (int32 per row, padded to whole int4s), written by plan_row
+    size_t sideOff, sideHdrOff;  // flat schedule: per window boundary the samples of the bundle that straddles it + a header (FLAT_* below)
+    int flatMaxTiles;   // flat schedule: windows of 32 consecutive samples at most (every bundle at S_max), per launch
     size_t pyr16Off;    // the half-precision copy of the feature pyramid the GDB_PREC_F16 render gathers from (PYR16_* below):
                         // 2 bytes per float of the fp32 pyramid, same (batch, view) stride and level offsets in elements
 };
@@ -88,6 +91,9 @@ struct WsLayout {
 #define PYR16_PLANE2(hw) (32u * (unsigned)(hw))   // byte offset of plane 2 inside a level of hw texels (plane 1 sits at 16 hw)
 
 #define SCAN_BLOCK 1024
+// flat schedule: floats per (sample, lane half) record of a straddling bundle: 20 pre-weight values (16 blended + 4 feat_head),
+// alpha, the depth term; padded to 24
+#define FLAT_REC 24
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -125,6 +131,12 @@ static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
     L.smapStride = L.planMW * L.planL + 32;
     L.smapOff = off; off = align_up(off + sizeof(uint32_t) * (size_t)f.B * f.H * L.smapStride, 256);
     L.nwinOff = off; off = align_up(off + sizeof(int32_t) * ((size_t)f.B * f.H + 8), 256);
+    // Flat schedule (GDB_SCHED_FLAT): the rows' sample lists read as ONE list, a wave = 32 consecutive samples of it; a bundle may
+    // straddle two windows, and then both waves leave its samples' records here for the fix-up launch (k_flat_fix).
+    L.nsampOff = off; off = align_up(off + sizeof(int32_t) * ((size_t)f.B * f.H + 8), 256);
+    L.flatMaxTiles = (int)((size_t)f.B * (((size_t)f.H * f.W * c.max_num_samples + 31) / 32 + 2));   // per batch item: tiles + 1 boundaries
+    L.sideHdrOff = off; off = align_up(off + sizeof(int32_t) * 2 * ((size_t)L.flatMaxTiles + 1), 256);
+    L.sideOff = off; off = align_up(off + sizeof(float) * FLAT_REC * 2 * (size_t)c.max_num_samples * ((size_t)L.flatMaxTiles + 1), 256);
     L.pyr16Off = off; off = align_up(off + (size_t)2 * L.pyrStride * f.B * f.V, 256);
     L.total = off;
     return L;
@@ -142,6 +154,8 @@ struct DevFrame {
     const int* plan;   // dense-schedule plan rows: [nwin, first bundle of window 0..nwin-1, W]
     const unsigned* smap; int smapStride;  // dense-schedule sample list, smapStride entries per row
     const int* nwin;   // dense-schedule windows in use per row
+    const int* nsamp;  // flat schedule: samples per row
+    float* side; int* side_hdr;  // flat schedule: straddling-bundle records and headers (written by the render, read by the fix-up)
     const float* cams;
     const float* pyr;
     const void* pyr16;  // half-precision pyramid (GDB_PREC_F16 gathers from it; built by gdb_prepare_ex or by the render call)
@@ -162,6 +176,8 @@ static inline DevFrame dev_frame(const GdbConfig& c, const GdbFrame& f, const Ws
     d.plan = (const int*)((const char*)ws + L.planOff);
     d.smap = (const unsigned*)((const char*)ws + L.smapOff); d.smapStride = L.smapStride;
     d.nwin = (const int*)((const char*)ws + L.nwinOff);
+    d.nsamp = (const int*)((const char*)ws + L.nsampOff);
+    d.side = (float*)((char*)ws + L.sideOff); d.side_hdr = (int*)((char*)ws + L.sideHdrOff);
     d.cams = (const float*)((const char*)ws + L.camsOff);
     d.pyr = (const float*)((const char*)ws + L.pyrOff);
     d.pyr16 = (const void*)((const char*)ws + L.pyr16Off);

@@ -225,7 +225,7 @@ struct PrepArgs {
     // dense-schedule plan: workgroups ntiles+1 .. ntiles+nplan, one wave per bundle-map row
     int nplan, S_max, adaptive, planL, planMW;
     const float* depth_range; int* plan;
-    unsigned* smap; int smapStride; int* nwin;
+    unsigned* smap; int smapStride; int* nwin; int* nsamp;
 };
 
 // One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, the row's
@@ -306,6 +306,7 @@ __device__ void plan_row(const PrepArgs& a, int rowid, int lane, unsigned* __res
         cprev_carry = __shfl(c, 63);
     }
     const int total = base;
+    if (lane == 0) a.nsamp[rowid] = total;   // (the flat schedule reads the rows' lists as one list)
     for (int s = total + lane; s < a.smapStride; s += 64) sm[s] = 0xFFFFFFFFu;  // past the row's last sample
     if (greedy) {
         if (lane == 0) atomicOr(&words[total >> 5], 1u << (total & 31));   // sentinel: the row ends where a bundle would start
@@ -505,7 +506,7 @@ int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipS
     a.B = f->B; a.H = f->H; a.W = f->W; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
     a.near_far = f->d_near_far; a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
-    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff);
+    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff); a.nsamp = (int*)((char*)ws + L.nsampOff);
     hipLaunchKernelGGL(k_plan, dim3((f->B * f->H + 3) / 4), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_plan");
     return GDB_OK;
@@ -556,7 +557,7 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     // the dense schedule's plan needs the depth prior; a frame prepared without it (build_rays / sample only) has none
     a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
-    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff);
+    a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff); a.nsamp = (int*)((char*)ws + L.nsampOff);
     // Built here (inside this launch, ~1 us) for adaptive configs whenever the frame carries its depth prior: a render call that
     // is told so (GDB_SCHED_PLAN_READY) uses it as it stands; any other dense render builds the plan itself (gdb_build_dense_plan,
     // a launch of its own on the same stream).

@@ -330,10 +330,11 @@ class HotPathEngine:
 
     def set_schedule(self, mode: int) -> None:
         """Work decomposition of THIS engine's fused calls (a per-call argument of the C ABI, no process-wide state):
-        0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment, 3 dense (one wave per <= 32 consecutive samples
-        of the compacted sample list).  See include/gdb_nerf_hip.h."""
-        if int(mode) not in (0, 1, 2, 3):
-            raise ValueError(f"schedule {mode} outside 0..3")
+        0 auto, 1 one wave per sample slot, 2 one wave per 32-bundle segment, 3 dense (one wave per window of whole bundles holding
+        <= 32 samples of the compacted sample list), 4 flat (one wave per 32 consecutive samples of it; bundles may straddle windows).
+        See include/gdb_nerf_hip.h."""
+        if int(mode) not in (0, 1, 2, 3, 4):
+            raise ValueError(f"schedule {mode} outside 0..4")
         self.schedule = int(mode)
 
     def feature_pyramid(self):

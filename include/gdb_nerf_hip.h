@@ -257,6 +257,8 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2
 #define GDB_SCHED_DENSE 3
+#define GDB_SCHED_FLAT 4 /* the compacted sample list cut into windows of exactly 32 consecutive samples (a bundle may straddle two
+                          * windows: a small second launch composites those); adaptive configs; what GDB_SCHED_AUTO takes for them */
 #define GDB_SCHED_PLAN_READY 0x100 /* flag: the dense plan in d_workspace was built by gdb_prepare from the current d_depth_range */
 #define GDB_SCHED_PYR16_READY 0x200 /* flag (GDB_PREC_F16): the half-precision pyramid in d_workspace was built by gdb_prepare_ex(GDB_PREP_PYR16)
                                      * for this frame; without it a GDB_PREC_F16 render first converts the fp32 pyramid (a launch of its own) */

@@ -48,7 +48,9 @@ def test_workspace_bytes_and_errors(lib):
     pyr = 3 * 20 * 4 * (256 * 320 + 128 * 160 + 64 * 80 + 32 * 40)
     # camera block + pyramid + its half-precision copy (GDB_PREC_F16's taps) + per-bundle counts / offsets (mirror) + dense plan +
     # sample list (4 B per sample offset of a row)
-    assert pyr + pyr // 2 < n.value < pyr + pyr // 2 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + 96 * 1024
+    # ... and the flat schedule's straddling-bundle records: (81920 x 3 / 32 + 3) boundaries x 3 samples x 2 lane halves x 24 floats, + headers
+    flat = (256 * 320 * 3 // 32 + 3) * (3 * 2 * 24 * 4 + 8)
+    assert pyr + pyr // 2 < n.value < pyr + pyr // 2 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + flat + 96 * 1024
     # reference error: network.py:33-34 ValueError('`Bundle size` must be a power of 2.')
     with pytest.raises(ValueError, match="power of 2"):
         _lib.check(lib.gdb_workspace_bytes(C.byref(_cfg(bundle_size=3)), C.byref(_shape()), C.byref(n)))

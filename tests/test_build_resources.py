@@ -33,7 +33,7 @@ def test_fused_kernels_keep_their_data_out_of_private_memory(usage):
 # slot loop for S_max > 8, where every wave-uniform value lives across the loop body; the segment-wave kernel re-derives them per slot)
 # (k_render_dense became a persistent tile loop in round 4: the tile cursor and the row / window / bundle range of the tile live in
 # SGPRs across gather + MLP, a few of which the allocator parks in VGPR lanes: 9-13 today)
-SGPR_SPILL_BOUND = {"k_render_fusedILb0": 0, "k_render_dense": 24, "k_render_solo": 40, "k_render_fusedILb1": 176}
+SGPR_SPILL_BOUND = {"k_render_fusedILb0": 0, "k_render_dense": 24, "k_render_flat": 32, "k_render_solo": 40, "k_render_fusedILb1": 176}
 
 
 def test_scalar_spills_stay_bounded_and_the_compiler_is_recorded(usage):

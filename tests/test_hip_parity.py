@@ -31,11 +31,11 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(params=[(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2)],
-                ids=["slot-waves-f16", "segment-wave-f16", "dense-f16", "slot-waves-f32", "segment-wave-f32", "dense-f32",
-                     "slot-waves-f32x", "segment-wave-f32x", "dense-f32x"])
+@pytest.fixture(params=[(1, 0), (2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 2), (2, 2), (3, 2), (4, 2)],
+                ids=["slot-waves-f16", "segment-wave-f16", "dense-f16", "flat-f16", "slot-waves-f32", "segment-wave-f32", "dense-f32", "flat-f32",
+                     "slot-waves-f32x", "segment-wave-f32x", "dense-f32x", "flat-f32x"])
 def mode(request):
-    """(schedule, precision): the three work decompositions of the fused kernel x the three MLP precisions
+    """(schedule, precision): the four work decompositions of the fused kernel x the three MLP precisions
     (include/gdb_nerf_hip.h GDB_SCHED_*, GDB_PREC_*).  Per-engine settings, passed on every call of the C ABI."""
     return request.param
 
@@ -398,7 +398,7 @@ def test_c2_full_size_against_the_oracle():
     eu = max_abs(npy(ubf), obf)
     print(f"c2 512x640 vs oracle: fp32 operator chain max abs err {eu:.3e}")
     assert eu <= 2e-4 and max_abs(npy(ud), od) <= 1e-4 * float(np.abs(od).max()) and max_abs(npy(uo), oo) <= 1e-5
-    for sched in (1, 2, 3):
+    for sched in (1, 2, 3, 4):
         for prec, tol in ((1, FUSED_TOL_F32), (2, FUSED_TOL_F32), (0, FUSED_TOL)):
             eng.set_schedule(sched)
             bf, depth, opac = eng.render(precision=prec)
@@ -509,13 +509,13 @@ def test_fused_schedules_agree_and_reject_bad_mode(prec):
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=4), max_num_samples=5, is_adaptive=True)
     eng.precision = prec
     eng.set_schedule(1); a = [t.clone() for t in eng.render()]
-    for other in (2, 3):
+    for other in (2, 3, 4):
         eng.set_schedule(other); b = [t.clone() for t in eng.render()]
         assert max_abs(npy(a[0]), npy(b[0])) <= 2e-6
         assert max_abs(npy(a[1]), npy(b[1])) <= 2e-6 * float(a[1].abs().max())
         assert max_abs(npy(a[2]), npy(b[2])) <= 2e-6
     with pytest.raises(ValueError, match="schedule"):
-        eng.set_schedule(4)
+        eng.set_schedule(5)
     eng.schedule = 7  # past the Python check: the C ABI rejects it before any launch
     with pytest.raises(ValueError, match="schedule"):
         eng.render()
@@ -531,7 +531,7 @@ def test_split_f16_precision_tracks_fp32(H, W, V, S, adaptive):
     Also against GDB_PREC_F16 as the yardstick: the split must be orders of magnitude closer to fp32 than f16 operands are."""
     frame = synthetic.make_frame(H, W, V=V, B=1, seed=21)
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=6), max_num_samples=S, is_adaptive=adaptive)
-    for sched in (1, 2, 3):
+    for sched in (1, 2, 3, 4):
         eng.set_schedule(sched)
         ref = [t.clone() for t in eng.render(precision=1)]
         x = [t.clone() for t in eng.render(precision=2)]
@@ -802,7 +802,7 @@ def test_fused_matches_fp32_chain_at_baseline_sizes(name, Ho, Wo, V, S, adaptive
 
 
 @pytest.mark.parametrize("offset", [30.0, 100.0])
-@pytest.mark.parametrize("sched", [1, 2, 3], ids=["slot-waves", "segment-wave", "dense"])
+@pytest.mark.parametrize("sched", [1, 2, 3, 4], ids=["slot-waves", "segment-wave", "dense", "flat"])
 def test_fp32_variance_over_views_on_large_magnitude_features(sched, offset):
     """the reference's `torch.var_mean` over the views (nerf.py:73) is two-pass; the fp32 core's one-pass form
     accumulates around a shift (d = g_v - g_0), so its cancellation is relative to the spread of g over the views, not to |g|^2.

@@ -11,7 +11,7 @@ import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(case, steps):
+def child(case, steps, schedule=3):
     sys.path.insert(0, ROOT)
     import time, torch
     from bench import WORKLOADS, PREC, to_dev
@@ -22,7 +22,7 @@ def child(case, steps):
     wl = WORKLOADS[wl_name]
     fr = to_dev(synthetic.make_frame(wl["Ho"], wl["Wo"], V=wl["V"], scene=wl["scene"], seed=0), dev)
     eng = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"], device=dev)
-    eng.set_schedule(3); eng.precision = PREC[prec]; eng.load_weights(synthetic.make_nerf_weights(seed=0))
+    eng.set_schedule(schedule); eng.precision = PREC[prec]; eng.load_weights(synthetic.make_nerf_weights(seed=0))
     eng.prepare(fr)
     nb = eng.n_bundles
     o = (torch.zeros((nb, eng.Q), device=dev), torch.zeros((nb,), device=dev), torch.zeros((nb,), device=dev))
@@ -48,11 +48,12 @@ def main():
     ap.add_argument("--persist", default="", help="comma list of GDB_DENSE_PERSIST values (1 = tile walk, 0 = one tile per wave) to run instead of --wgs: "
                                                   "the launcher's two forms against each other, whatever its policy picks")
     ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--schedule", type=int, default=3, help="3 dense (windows of whole bundles), 4 flat (32 consecutive samples)")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
-        return child(a.case, a.steps)
+        return child(a.case, a.steps, a.schedule)
     sys.path.insert(0, ROOT)
     import gdb_nerf_amd  # noqa: F401
     from gdb_nerf_amd import build as _b
@@ -65,7 +66,7 @@ def main():
             env = dict(os.environ, GDB_NERF_LIB=lib)
             env.pop("GDB_DENSE_WGS_PER_CU", None); env.pop("GDB_DENSE_PERSIST", None)
             env.update(extra)
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--case", a.case, "--steps", str(a.steps)],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--case", a.case, "--steps", str(a.steps), "--schedule", str(a.schedule)],
                                env=env, capture_output=True, text=True, timeout=300)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:

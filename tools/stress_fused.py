@@ -18,7 +18,7 @@ for i in range(N):
     eng.load_weights(synthetic.make_nerf_weights(seed=i))
     eng.prepare({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in frame.items()})
     ubf, ud, uo = [t.cpu().numpy() for t in eng.render_unfused()]
-    for sched in (1, 2, 3):
+    for sched in (1, 2, 3, 4):
         eng.set_schedule(sched)
         for prec, tol in ((1, 1e-3), (2, 1e-3), (0, 3e-3)):
             bf, d, o = [t.cpu().numpy() for t in eng.render(precision=prec)]
