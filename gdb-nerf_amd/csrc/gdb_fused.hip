@@ -2323,57 +2323,68 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
 // in-wave composite's arithmetic: transmittance as the product over the earlier samples nearest first, weights alpha x T, the sums
 // right-nested (S_max <= 4: the Horner chain) or by doubling (S_max > 4: the ds_bpermute steps).
 // NS = slots unrolled (registers, all records requested up front: one memory round trip behind the header's): 4 for S_max <= 4, 16 else.
+// One wave takes FIX_PER_WAVE consecutive boundaries, all their records requested before the first is used (the kernel is a launch
+// ramp and two dependent memory round trips long, not arithmetic: fewer, fatter waves).
+#define FIX_PER_WAVE 4
 template <int NS>
 __global__ void __launch_bounds__(256) k_flat_fix(FusedArgs a) {
 #pragma clang fp contract(off)
     const DevFrame& f = a.f;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-    const int b = (int)blockIdx.x * 4 + wv + 1;           // boundary behind tile b - 1 (boundaries behind the list's end are marked empty)
-    if (b > a.flat_last) return;                           // (the grid's last workgroup may reach past the worst case)
     const int S = f.S_max;
-    float val[NS], alv[NS], ztv[NS];
-    const float* r0 = flat_rec(f, a.flat_base + b, 0, h);
-    const int gb = ((const int*)r0)[22], cnt = ((const int*)r0)[23];   // the header rides in slot 0's padding (written by the tail side)
+    const int b0 = ((int)blockIdx.x * 4 + wv) * FIX_PER_WAVE + 1;   // boundary b sits behind tile b - 1 (those behind the list's end are marked empty)
+    float val[FIX_PER_WAVE][NS], alv[FIX_PER_WAVE][NS], ztv[FIX_PER_WAVE][NS];
+    int gbv[FIX_PER_WAVE], cntv[FIX_PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {   // every slot the config can have, unconditionally: ONE round trip (slots past the count are unused)
-        const float* r = r0 + (size_t)min(k, S - 1) * 2 * FLAT_REC;
-        alv[k] = r[20]; ztv[k] = r[21]; val[k] = r[i < 20 ? i : 0];
+    for (int q = 0; q < FIX_PER_WAVE; ++q) {
+        const int b = min(b0 + q, a.flat_last);   // (clamped: the grid's last wave may reach past the worst case; skipped below)
+        const float* r0 = flat_rec(f, a.flat_base + b, 0, h);
+        gbv[q] = ((const int*)r0)[22]; cntv[q] = ((const int*)r0)[23];   // the header rides in slot 0's padding (written by the tail side)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {   // every slot the config can have, unconditionally (slots past the count are unused)
+            const float* r = r0 + (size_t)min(k, S - 1) * 2 * FLAT_REC;
+            alv[q][k] = r[20]; ztv[q][k] = r[21]; val[q][k] = r[i < 20 ? i : 0];
+        }
     }
-    if (gb < 0 || cnt < 2 || cnt > S || cnt > NS || gb >= f.H * f.W) return;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        float Tr = 1.f;
+    for (int q = 0; q < FIX_PER_WAVE; ++q) {
+        const int gb = gbv[q], cnt = cntv[q];
+        if (b0 + q > a.flat_last || gb < 0 || cnt < 2 || cnt > S || cnt > NS || gb >= f.H * f.W) continue;
 #pragma unroll
-        for (int d = 1; d <= k; ++d) if (S > 4 ? d < S : d < 4) Tr *= 1.f - alv[k - d];
-        const float w = alv[k] * Tr;
-        val[k] = i < 20 ? w * val[k] : (i == 20 ? w : w * ztv[k]);
-    }
-    float acc;
-    if (S <= 4) {
-        acc = 0.f;
-        bool started = false;
+        for (int k = 0; k < NS; ++k) {
+            float Tr = 1.f;
 #pragma unroll
-        for (int k = NS - 1; k >= 0; --k)
-            if (k < cnt) { acc = started ? val[k] + acc : val[k]; started = true; }
-    } else {
+            for (int d = 1; d <= k; ++d) if (S > 4 ? d < S : d < 4) Tr *= 1.f - alv[q][k - d];
+            const float w = alv[q][k] * Tr;
+            val[q][k] = i < 20 ? w * val[q][k] : (i == 20 ? w : w * ztv[q][k]);
+        }
+        float acc;
+        if (S <= 4) {
+            acc = 0.f;
+            bool started = false;
 #pragma unroll
-        for (int d = 1; d < NS; d <<= 1)
-            if (d < S) {
+            for (int k = NS - 1; k >= 0; --k)
+                if (k < cnt) { acc = started ? val[q][k] + acc : val[q][k]; started = true; }
+        } else {
 #pragma unroll
-                for (int k = 0; k + d < NS; ++k) if (k + d < cnt) val[k] = val[k] + val[k + d];   // ascending k reads the not yet updated k + d
-            }
-        acc = val[0];
-    }
-    const float wsum = __shfl(acc, (h << 5) | 20), rden = 1.f / fmaxf(wsum, 1e-6f);
-    const size_t row = (size_t)(a.f.B > 1 ? a.row_lo / f.H : 0) * f.H * f.W + (size_t)gb;
-    int ch = -1;
-    if (i < 16) ch = own_chan(h, i);
-    else if (i < 20) ch = NBLEND + 4 * h + (i - 16);
-    if (ch >= 0) a.bf[row * a.ldo + ch] = acc * rden;
-    if (h == 0 && i == 20) { if (a.ldo == NOUT) a.opac[row] = acc * rden; else a.bf[row * a.ldo + NOUT + 1] = acc * rden; }
-    if (h == 0 && i == 21) {
-        const float d = acc * rden, dd = f.inv_depth ? 1.f / d : d;
-        if (a.ldo == NOUT) a.depth[row] = dd; else a.bf[row * a.ldo + NOUT] = dd;
+            for (int d = 1; d < NS; d <<= 1)
+                if (d < S) {
+#pragma unroll
+                    for (int k = 0; k + d < NS; ++k) if (k + d < cnt) val[q][k] = val[q][k] + val[q][k + d];   // ascending k reads the not yet updated k + d
+                }
+            acc = val[q][0];
+        }
+        const float wsum = __shfl(acc, (h << 5) | 20), rden = 1.f / fmaxf(wsum, 1e-6f);
+        const size_t row = (size_t)(a.f.B > 1 ? a.row_lo / f.H : 0) * f.H * f.W + (size_t)gb;
+        int ch = -1;
+        if (i < 16) ch = own_chan(h, i);
+        else if (i < 20) ch = NBLEND + 4 * h + (i - 16);
+        if (ch >= 0) a.bf[row * a.ldo + ch] = acc * rden;
+        if (h == 0 && i == 20) { if (a.ldo == NOUT) a.opac[row] = acc * rden; else a.bf[row * a.ldo + NOUT + 1] = acc * rden; }
+        if (h == 0 && i == 21) {
+            const float d = acc * rden, dd = f.inv_depth ? 1.f / d : d;
+            if (a.ldo == NOUT) a.depth[row] = dd; else a.bf[row * a.ldo + NOUT] = dd;
+        }
     }
 }
 
@@ -2538,8 +2549,9 @@ static hipError_t launch_flat_n(FusedArgs& a, size_t lds, int max_tiles_per_item
         else hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (a.f.S_max <= 4) hipLaunchKernelGGL(k_flat_fix<4>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_flat_fix<GDB_MAX_SAMPLES>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+        const unsigned fix_grid = (unsigned)((tiles + 4 * FIX_PER_WAVE - 1) / (4 * FIX_PER_WAVE));
+        if (a.f.S_max <= 4) hipLaunchKernelGGL(k_flat_fix<4>, dim3(fix_grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_flat_fix<GDB_MAX_SAMPLES>, dim3(fix_grid), dim3(256), 0, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

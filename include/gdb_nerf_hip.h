@@ -240,8 +240,13 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  * schedule (work decomposition; results agree to rounding): GDB_SCHED_AUTO picks by shape, GDB_SCHED_SLOT_WAVES =
  *   one wave per sample slot with the composite through LDS, GDB_SCHED_SEGMENT_WAVE = one wave walks all slots of
  *   its 32 bundles with the composite in registers, GDB_SCHED_DENSE = the reference's compacted sample list
- *   (bundle_sampler.py:182-189): one wave per <= 32 consecutive samples of a bundle-map row, composite across lanes
- *   (GDB_SCHED_AUTO takes it for adaptive counts.  It needs the per-row plan + sample list in d_workspace: by default the render
+ *   (bundle_sampler.py:182-189): one wave per window of WHOLE consecutive bundles of a bundle-map row holding <= 32 samples,
+ *   composite across lanes; GDB_SCHED_FLAT = the same list read as one list over the rows and cut into windows of EXACTLY 32
+ *   consecutive samples (4-8 % fewer waves; a bundle may straddle two windows - both waves then leave its samples' records in
+ *   d_workspace and a small second launch composites it with the in-wave composite's own arithmetic, bit for bit: the result
+ *   does not depend on where the windows fall, row strips equal the full render; bit-identical to GDB_SCHED_DENSE).
+ *   (GDB_SCHED_AUTO takes DENSE for adaptive counts, FLAT where it measured faster: fp32, S_max <= 4, frames of few tiles per
+ *   wave slot.  Both need the per-row plan + sample list in d_workspace: by default the render
  *   call builds them itself from frame->d_depth_range, a small launch of its own on the same stream — the one place a render
  *   call writes the workspace.  gdb_prepare builds the same plan inside its own launch when the frame it is given carries
  *   d_depth_range and the config is adaptive; a caller that has NOT changed the contents of d_depth_range since that
@@ -257,8 +262,7 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
 #define GDB_SCHED_SLOT_WAVES 1
 #define GDB_SCHED_SEGMENT_WAVE 2
 #define GDB_SCHED_DENSE 3
-#define GDB_SCHED_FLAT 4 /* the compacted sample list cut into windows of exactly 32 consecutive samples (a bundle may straddle two
-                          * windows: a small second launch composites those); adaptive configs; what GDB_SCHED_AUTO takes for them */
+#define GDB_SCHED_FLAT 4 /* (needs W x S_max < 65536, B x H < 65536, H x W < 2^24; GDB_E_SHAPE otherwise) */
 #define GDB_SCHED_PLAN_READY 0x100 /* flag: the dense plan in d_workspace was built by gdb_prepare from the current d_depth_range */
 #define GDB_SCHED_PYR16_READY 0x200 /* flag (GDB_PREC_F16): the half-precision pyramid in d_workspace was built by gdb_prepare_ex(GDB_PREP_PYR16)
                                      * for this frame; without it a GDB_PREC_F16 render first converts the fp32 pyramid (a launch of its own) */

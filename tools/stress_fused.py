@@ -1,4 +1,4 @@
-"""One-off stress: N seeded random shapes x the three schedules x the three precisions, fused kernel vs the fp32 operator chain (same checks as
+"""One-off stress: N seeded random shapes x the four schedules x the three precisions, fused kernel vs the fp32 operator chain (same checks as
 tests/test_hip_parity.py::test_fused_random_shapes_vs_fp32_chain).  usage: stress_fused.py [N] [seed]"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,19 +28,25 @@ for i in range(N):
             if not (e <= tol and eo <= 1e-5):
                 bad += 1
                 print(f"FAIL case {i} {Ho}x{Wo} {c} schedule {sched} precision {prec}: bundle_feat err {e:.3e}, opacity err {eo:.3e}", flush=True)
-    eng.set_schedule(0)
-    # GDB_SCHED_AUTO, packed rows, two row strips cut at a random row against the whole frame: bit for bit (the multi-GPU unit)
+    # GDB_SCHED_AUTO and the flat schedule (whose windows fall differently in every strip), packed rows, two row strips cut at a
+    # random row against the whole frame: bit for bit (the multi-GPU unit); and flat against dense: bit for bit
     H = Ho // 2
-    full = eng.render_packed(precision=1).clone()
     cut = int(rng.integers(0, H + 1))
-    part = torch.full_like(full, float("nan"))
-    eng.render_packed(0, cut, 1, part); eng.render_packed(cut, H, 1, part)
-    if not torch.equal(full, part):
-        bad += 1
-        print(f"FAIL case {i} {Ho}x{Wo} {c}: row strips [0,{cut}) + [{cut},{H}) differ from the full frame", flush=True)
+    eng.set_schedule(3); dense = eng.render_packed(precision=1).clone()
+    for sch in (4, 0):
+        eng.set_schedule(sch)
+        full = eng.render_packed(precision=1).clone()
+        part = torch.full_like(full, float("nan"))
+        eng.render_packed(0, cut, 1, part); eng.render_packed(cut, H, 1, part)
+        if not torch.equal(full, part):
+            bad += 1
+            print(f"FAIL case {i} {Ho}x{Wo} {c} schedule {sch}: row strips [0,{cut}) + [{cut},{H}) differ from the full frame", flush=True)
+        if sch == 4 and not torch.equal(full, dense):
+            bad += 1
+            print(f"FAIL case {i} {Ho}x{Wo} {c}: flat differs from dense (max {float((full - dense).abs().max()):.3e})", flush=True)
     if not (np.abs(full[:, :39].cpu().numpy() - ubf).max() <= 1e-3):
         bad += 1
         print(f"FAIL case {i} {Ho}x{Wo} {c}: packed AUTO render off the fp32 chain", flush=True)
     if i % 50 == 49: print(f"{i + 1} cases, worst err so far {worst:.3e}, failures {bad}", flush=True)
-print(f"done: {N} cases x 3 schedules x 3 precisions, worst fp32-grade bundle_feat err {worst:.3e}, failures {bad}")
+print(f"done: {N} cases x 4 schedules x 3 precisions, worst fp32-grade bundle_feat err {worst:.3e}, failures {bad}")
 sys.exit(1 if bad else 0)
