@@ -63,6 +63,7 @@ _SIGNATURES = {
     "gdb_render_weights": (C.c_int, [_CFG, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "gdb_accumulate": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "gdb_build_feature_volume": (C.c_int, [_P] * 6 + [C.c_int32] * 9 + [_P, _P, _P]),
+    "gdb_build_feature_volume_ws": (C.c_int, [_P] * 6 + [C.c_int32] * 9 + [_P, _P, _P, _P]),
     "gdb_depth_regression": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gdb_render_bundles_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

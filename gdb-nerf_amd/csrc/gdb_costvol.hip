@@ -64,7 +64,18 @@ struct CostVolArgs {
     const float* feat; const float* proj; const float* depth_values; float* out;
 };
 
-template <int VT>  // number of source views: the per-view tap state lives in registers
+// Channel-pair re-layout of the source maps for the PAIR form of k_costvol: (B*V, C, Hs, Ws) -> (B*V, C / 2, Hs, Ws, 2), so that one
+// 16-byte load at (y, x) holds the x pair of TWO channels.  One thread per (map, channel pair, y, x): two coalesced 4-byte loads, one
+// 8-byte store.  15.7 MB at the 256x320 stage: ~5 us, a third of what it saves the sweep (profiles/r04/costvol_pair_layout.txt).
+__global__ void __launch_bounds__(256) k_costvol_pairs(const float* __restrict__ src, float2* __restrict__ dst, size_t plane, size_t npairs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npairs * plane) return;
+    const size_t pc = t / plane, p = t - pc * plane;   // pc = map * (C / 2) + channel pair
+    dst[t] = make_float2(src[(2 * pc) * plane + p], src[(2 * pc + 1) * plane + p]);
+}
+
+// PAIR: a.feat is the channel-pair-interleaved copy (k_costvol_pairs; C even): per (row, view) ONE 16-byte load serves two channels.
+template <int VT, bool PAIR>  // VT = number of source views: the per-view tap state lives in registers
 __global__ void __launch_bounds__(256) k_costvol(CostVolArgs a) {
     // 1-D grid over (batch, tile of 256 voxels of the flattened (y,x) plane, depth plane, channel group), depth
     // innermost, remapped so that each XCD (blocks b, b+8, ...) walks one contiguous band: the D planes of a tile
@@ -118,6 +129,31 @@ __global__ void __launch_bounds__(256) k_costvol(CostVolArgs a) {
     }
     const size_t plane = (size_t)a.Hs * a.Ws, ovol = (size_t)a.D * a.Ht * a.Wt;
     const float invV = 1.f / (float)a.V;
+    if constexpr (PAIR) {
+        // [c / 2][y][x][2]: the 16 bytes at (y, xs) are (c @ xs, c + 1 @ xs, c @ xs + 1, c + 1 @ xs + 1); same products, same order of
+        // sums as the planar form below: bit-identical results
+        struct F4c { float x, y, z, w; } __attribute__((packed, aligned(8)));
+        for (int c = c_begin; c < c_end; c += 2) {
+            float val[2][VT], mean[2] = {0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const float* pl = a.feat + (((size_t)b * a.V + v) * a.C + c) * plane;   // start of the pair's interleaved plane (2 plane floats)
+                const F4c t0 = *(const F4c*)(pl + 2 * (size_t)off0[v]), t1 = *(const F4c*)(pl + 2 * (size_t)off1[v]);
+                val[0][v] = t0.x * w00[v] + t0.z * w01[v] + t1.x * w10[v] + t1.z * w11[v];
+                val[1][v] = t0.y * w00[v] + t0.w * w01[v] + t1.y * w10[v] + t1.w * w11[v];
+                mean[0] += val[0][v]; mean[1] += val[1][v];
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float m = mean[e] * invV;
+                float var = 0.f;
+#pragma unroll
+                for (int v = 0; v < VT; ++v) { float d = val[e][v] - m; var += d * d; }
+                a.out[((size_t)b * a.C + c + e) * ovol + vox] = var * invV;
+            }
+        }
+        return;
+    }
     for (int c = c_begin; c < c_end; ++c) {
         float val[VT], mean = 0.f;
 #pragma unroll
@@ -143,10 +179,31 @@ __global__ void __launch_bounds__(256) k_costvol(CostVolArgs a) {
     }
 }
 
+static int build_feature_volume(const float* d_src_feat, const float* d_src_exts, const float* d_src_ints,
+                                const float* d_tar_exts, const float* d_tar_ints, const float* d_depth_values,
+                                int32_t B, int32_t V, int32_t C, int32_t Hs, int32_t Ws, int32_t D, int32_t Ht, int32_t Wt,
+                                int32_t inv_depth, float* d_proj_ws, float* d_pair_ws, float* d_out, void* stream_);
+
 extern "C" int gdb_build_feature_volume(const float* d_src_feat, const float* d_src_exts, const float* d_src_ints,
                                         const float* d_tar_exts, const float* d_tar_ints, const float* d_depth_values,
                                         int32_t B, int32_t V, int32_t C, int32_t Hs, int32_t Ws, int32_t D, int32_t Ht, int32_t Wt,
                                         int32_t inv_depth, float* d_proj_ws, float* d_out, void* stream_) {
+    return build_feature_volume(d_src_feat, d_src_exts, d_src_ints, d_tar_exts, d_tar_ints, d_depth_values, B, V, C, Hs, Ws, D, Ht, Wt, inv_depth,
+                                d_proj_ws, nullptr, d_out, stream_);
+}
+
+extern "C" int gdb_build_feature_volume_ws(const float* d_src_feat, const float* d_src_exts, const float* d_src_ints,
+                                           const float* d_tar_exts, const float* d_tar_ints, const float* d_depth_values,
+                                           int32_t B, int32_t V, int32_t C, int32_t Hs, int32_t Ws, int32_t D, int32_t Ht, int32_t Wt,
+                                           int32_t inv_depth, float* d_proj_ws, float* d_pair_ws, float* d_out, void* stream_) {
+    return build_feature_volume(d_src_feat, d_src_exts, d_src_ints, d_tar_exts, d_tar_ints, d_depth_values, B, V, C, Hs, Ws, D, Ht, Wt, inv_depth,
+                                d_proj_ws, d_pair_ws, d_out, stream_);
+}
+
+static int build_feature_volume(const float* d_src_feat, const float* d_src_exts, const float* d_src_ints,
+                                const float* d_tar_exts, const float* d_tar_ints, const float* d_depth_values,
+                                int32_t B, int32_t V, int32_t C, int32_t Hs, int32_t Ws, int32_t D, int32_t Ht, int32_t Wt,
+                                int32_t inv_depth, float* d_proj_ws, float* d_pair_ws, float* d_out, void* stream_) {
     if (!d_src_feat || !d_src_exts || !d_src_ints || !d_tar_exts || !d_tar_ints || !d_depth_values || !d_proj_ws || !d_out)
         return gdb_fail(GDB_E_BADARG, "NULL pointer");
     if (B < 1 || V < 1 || C < 1 || Hs < 1 || Ws < 2 || D < 1 || Ht < 1 || Wt < 1) return gdb_fail(GDB_E_SHAPE, "bad cost-volume shape");
@@ -164,17 +221,35 @@ extern "C" int gdb_build_feature_volume(const float* d_src_feat, const float* d_
     const int tiles = (Ht * Wt + 255) / 256, groups = (C + cpt - 1) / cpt;
     if ((size_t)B * tiles * D * groups >= ((size_t)1 << 31)) return gdb_fail(GDB_E_SHAPE, "cost volume too large for the launch grid");
     const int nblk = B * tiles * D * groups;
-    CostVolArgs a{B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt, tiles, nblk, d_src_feat, d_proj_ws, d_depth_values, d_out};
+    // The channel-pair form: given C * Hs * Ws * V * B floats of scratch (gdb_build_feature_volume_ws) and an even channel count, the
+    // source maps are re-laid once ([c / 2][y][x][2], k_costvol_pairs) and the sweep loads 16 bytes per (channel PAIR, row, view)
+    // instead of 8 per (channel, row, view): half the load instructions of a kernel the texture addresser bounds.  Bit-identical.
+    const bool pair = d_pair_ws != nullptr && (C % 2) == 0 && (cpt % 2) == 0 && V <= 4;   // (5..8 views: the doubled tap state leaves the registers)
+    if (pair) {
+        const size_t plane = (size_t)Hs * Ws, npairs = (size_t)B * V * (C / 2);
+        hipLaunchKernelGGL(k_costvol_pairs, dim3((unsigned)((npairs * plane + 255) / 256)), dim3(256), 0, st, d_src_feat, (float2*)d_pair_ws, plane, npairs);
+        LAUNCH_CHECK("k_costvol_pairs");
+    }
+    CostVolArgs a{B, V, C, Hs, Ws, D, Ht, Wt, inv_depth, cpt, tiles, nblk, pair ? d_pair_ws : d_src_feat, d_proj_ws, d_depth_values, d_out};
     const dim3 grid((nblk + 7) / 8 * 8), blk(256);
-    switch (V) {
-        case 1: hipLaunchKernelGGL(k_costvol<1>, grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(k_costvol<2>, grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(k_costvol<3>, grid, blk, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(k_costvol<4>, grid, blk, 0, st, a); break;
-        case 5: hipLaunchKernelGGL(k_costvol<5>, grid, blk, 0, st, a); break;
-        case 6: hipLaunchKernelGGL(k_costvol<6>, grid, blk, 0, st, a); break;
-        case 7: hipLaunchKernelGGL(k_costvol<7>, grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL(k_costvol<8>, grid, blk, 0, st, a); break;
+    if (pair) {
+        switch (V) {
+            case 1: hipLaunchKernelGGL((k_costvol<1, true>), grid, blk, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((k_costvol<2, true>), grid, blk, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((k_costvol<3, true>), grid, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL((k_costvol<4, true>), grid, blk, 0, st, a); break;
+        }
+    } else {
+        switch (V) {
+            case 1: hipLaunchKernelGGL((k_costvol<1, false>), grid, blk, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((k_costvol<2, false>), grid, blk, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((k_costvol<3, false>), grid, blk, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((k_costvol<4, false>), grid, blk, 0, st, a); break;
+            case 5: hipLaunchKernelGGL((k_costvol<5, false>), grid, blk, 0, st, a); break;
+            case 6: hipLaunchKernelGGL((k_costvol<6, false>), grid, blk, 0, st, a); break;
+            case 7: hipLaunchKernelGGL((k_costvol<7, false>), grid, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL((k_costvol<8, false>), grid, blk, 0, st, a); break;
+        }
     }
     LAUNCH_CHECK("k_costvol");
     return GDB_OK;

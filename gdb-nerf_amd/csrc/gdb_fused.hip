@@ -2154,7 +2154,11 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
+#ifdef GDB_DEBUG_STAMPS  // one stamp record per (wave slot, tile iteration)
+    unsigned* dbg = a.dbg ? a.dbg + (size_t)it * gridDim.x * (16 * 16 * 2) : nullptr;
+#else
     unsigned* dbg = nullptr; (void)dbg;
+#endif
     // ---- tile -> (first row, offset in that row); the rows the window covers ------------------------------------------------
     const unsigned desc = (unsigned)__builtin_amdgcn_readlane((int)vdesc, it);
     if (desc == 0xFFFFFFFFu) continue;
@@ -2186,6 +2190,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
 #pragma unroll
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
+    STAMP(0);
     const int mx = min((int)(m & 0xFFFFu), f.W - 1), k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
     const int row_l = my_row - bi * f.H;             // this lane's bundle-map row inside its batch item
     const int gbl = row_l * f.W + mx;                // ... and its bundle index inside the batch item's map (< 2^24, checked by the launcher)
@@ -2207,8 +2212,10 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
         Bundle<4> q;
         load_bundle<4, true, false>(f, tc, bi, row_l, mx, q);
         q.count = min(max(mcnt, 1), f.S_max);
+        STAMP(1);
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
+    STAMP(2);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
@@ -2294,6 +2301,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
             }
         }
     }
+    STAMP(7);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     // the window's WHOLE bundles (columns hp .. nb - 1 - tp) to the output record, column 0 = the first whole one
@@ -2313,6 +2321,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     if (ncol > 0) out_copy(a, o, (size_t)bi * f.H * f.W + (size_t)(first + hp), ncol, lane);
+    STAMP(8); STAMP(9);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     } while (PERSIST && ++it < ntile);

@@ -55,6 +55,10 @@ def test_hip_cost_volume_matches_reference(f8, tag):
     e = max_abs(vol.cpu().numpy(), c["volume"])
     print(f"cost volume {tag}: max abs err {e:.3e}")
     assert e <= 1e-4
+    # the default takes the channel-pair re-layout of the source maps (gdb_build_feature_volume_ws); the planar form: bit-identical
+    planar = costvol.build_feature_volume(t("src_feat"), t("src_exts"), t("src_ints"), t("tar_ext"), t("tar_int"), t("depth_values"), bool(c["inv_depth"]),
+                                          pair_layout=False)
+    assert torch.equal(vol, planar)
     d, ci = costvol.depth_regression(t("depth_values"), t("prob"), 1.0, bool(c["inv_depth"]))
     assert max_abs(d.cpu().numpy(), c["depth"]) <= 1e-5 * float(np.abs(c["depth"]).max())
     assert max_abs(ci.cpu().numpy(), c["ci"]) <= 1e-5 * float(np.abs(c["ci"]).max())

@@ -4,14 +4,14 @@
 #      (tools/profile_round.sh), occupancy / phase stamps of the fp32 kernel, the decoder and whole-network benches.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 echo "== driver-like (20 steps)"; timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_like_20_steps.json 2> $OUT/bench_driver_like.err
 echo "== default";                timeout -k 10 500 python3 bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "== all workloads";          BENCH_STEPS=300 timeout -k 10 900 bash tools/bench_all.sh > $OUT/bench_all_workloads.json 2> $OUT/bench_all.err
-echo "== stamps";                 for s in 1 3; do timeout -k 10 120 python3 tools/stamps.py --schedule=$s 2>&1 | grep -v -i warn > $OUT/stamps_f32_schedule$s.txt; done
+echo "== stamps";                 for s in 1 3 4; do timeout -k 10 120 python3 tools/stamps.py --schedule=$s 2>&1 | grep -v -i warn > $OUT/stamps_f32_schedule$s.txt; done
 timeout -k 10 120 python3 tools/stamps.py --schedule=3 f16 2>&1 | grep -v -i warn > $OUT/stamps_f16_schedule3.txt
 echo "== small-operand probe";    timeout -k 10 200 python3 tools/probe_split_f16_small.py > $OUT/split_f16_small_operands.txt 2>&1
 echo "== decoder / network";      timeout -k 10 300 python3 tools/bench_decoder.py > $OUT/bench_decoder.json 2> $OUT/bench_decoder.err

@@ -28,10 +28,10 @@ raw12 = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :12].astype(np.int64).res
 raw12 = raw12[(raw12[:, 0] > 0) & (raw12[:, 9] > 0)]
 raw = raw12[:, :10]
 t = raw.reshape(-1, 10)
-if sched != 3:
+if sched not in (3, 4):
     t[:, 1] = t[:, 0]
 t = t[(t[:, 0] > 0) & (t[:, 9] > 0)]
-names = ["(dense: plan + sample map)" if sched == 3 else "(unused)", "bundle+vox+gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
+names = ["(dense / flat: plan + sample map)" if sched in (3, 4) else "(unused)", "bundle+vox+gather 3 views", "MLP mean/var+base", "MLP agg+fc", "MLP lr0+fh+shared", "MLP blend pass", "hand-off", "wait barrier", "composite+store"]
 full = t[t[:, 6] > 0]  # waves that ran a slot
 d = np.diff(full, axis=1).astype(np.float64)
 tot = (full[:, 9] - full[:, 0]).mean()
