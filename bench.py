@@ -329,24 +329,24 @@ def ev_ms(pairs):
     return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else None
 
 
-def hot_ms(timed, prep_fn, step_fn, n=200):
-    """GPU time of the render launches of one step in the steady state of the step loop: n back-to-back steps (prepare + render)
-    and n prepare-only steps, each run between ONE pair of HIP events on the launch stream, the difference per step.  (An event pair
-    around every render instead leaves the host between the render's launches and the events: with two launches per render - the
-    flat schedule's k_render_flat + k_flat_fix - it read 110 us where rocprofv3 has 92.9 + 5.1.)  Inputs come from the HBM frame ring
-    in both loops."""
-    def loop(fn):
-        for _ in range(20):
-            fn()
-        timed.sync()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        timed.sync()
-        return e0.elapsed_time(e1) / n
-    return loop(step_fn) - loop(prep_fn)
+def hot_ms(timed, render_fn, n=200):
+    """GPU time of the render's launches (the dominant kernel, + the flat schedule's 5 us fix-up launch where that schedule runs): n
+    back-to-back render calls on the frame last prepared, between ONE pair of HIP events on the launch stream.  The calls queue up
+    behind each other (a render is ~100 us of GPU time, its host side ~10 us), so the figure is GPU time including the launch gaps
+    a render really has.  Its inputs are cache-warm, unlike the timed region's (frames cycled through the HBM ring): rocprofv3's
+    average over the timed region reads 2-3 % above it (profiles/).  (An event pair around every render of the step loop instead
+    leaves event packets between the launches: with two launches per render it read 110 us where rocprofv3 has 92.9 + 5.1; the
+    difference of a step loop and a prepare-only loop under-reads, because a prepare-only step is host-bound.)"""
+    for _ in range(20):
+        render_fn()
+    timed.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        render_fn()
+    e1.record()
+    timed.sync()
+    return e0.elapsed_time(e1) / n
 
 
 def main():
@@ -514,7 +514,7 @@ def main():
     if world == 1:
         dt = timed.run(step_frame, args.warmup, args.steps)
         if args.path == "fused" and args.streams == 1:
-            kern_fused_ms = hot_ms(timed, lambda: eng.prepare(next_frame()), lambda: step_frame(False))
+            kern_fused_ms = hot_ms(timed, lambda: eng.render(0, H, None, out))
         else:
             timed.sample(step_frame)
         rays_per_step, share = Ho * Wo, 1.0
@@ -597,9 +597,10 @@ def main():
     roof.update({"traffic": traffic, "traffic_source": tsrc, "kernel_ms": kern_ms, "alg_bytes": ab, "alg_flops": af, "n_samples": n_samples,
                  "kernel_samples": 200 if kern_fused_ms is not None else (len(kern_pairs) if world == 1 else None),
                  "note": "achieved = ALGORITHMIC bytes / flops (SURVEY.md §8(d)) per frame / kernel_ms; kernel_ms = GPU time of the render's "
-                         "launches per step (the dominant kernel + the flat schedule's 5 us fix-up launch where that schedule runs): 200 "
-                         "back-to-back steps minus 200 prepare-only steps, one HIP event pair each on the launch stream, untimed, right "
-                         "after the timed region (N > 1: event pairs around the render on 40 sampled steps)"})
+                         "launches (the dominant kernel + the flat schedule's 5 us fix-up launch where that schedule runs): 200 back-to-back "
+                         "render calls between one HIP event pair on the launch stream, untimed, right after the timed region, inputs "
+                         "cache-warm (rocprofv3's average over the HBM-ring steps: profiles/; N > 1: event pairs around the render on 40 "
+                         "sampled steps)"})
 
     res = {
         "metric": "rendered rays/sec, GDB-NeRF hot path (sample+fetch+MLP+composite)", "value": value, "unit": "rays/s",
@@ -635,7 +636,7 @@ def main():
             fn2 = lambda smp: step_frame(smp, PREC[other], pairs2)
             timed.rewarm(fn2, 100.0)
             dt2 = timed.run(fn2, 50, k2)
-            km2 = hot_ms(timed, lambda: eng.prepare(next_frame()), lambda: fn2(False))
+            km2 = hot_ms(timed, lambda: eng.render(0, H, PREC[other], out))
             obf = eng.render(0, H, PREC[other])[0]
             return {"dtype": DTYPE[other], "precision": other, "value": Ho * Wo * k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
                     "steps": k2, "kernel_ms": km2, "hbm_frac": ab / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -657,7 +658,7 @@ def main():
             fn8 = lambda smp: step_frame(smp, prec, pairs8, e8, o8)
             timed.rewarm(fn8, 100.0)
             dt8 = timed.run(fn8, 50, k2)
-            km8 = hot_ms(timed, lambda: e8.prepare(next_frame()), lambda: fn8(False))
+            km8 = hot_ms(timed, lambda: e8.render(0, H, prec, o8))
             ns8 = int(e8.sample()["total"].item())
             af8 = alg_flops(ns8, V)
             sched8 = args.schedule or (3 if adaptive else (1 if smax <= 3 else 2))   # (S_max 8: never the flat schedule under AUTO)

@@ -24,7 +24,13 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); eng.render(); e1.record(); torch.cuda.synchronize()
 launch_us = e0.elapsed_time(e1) * 1e3
 lib.gdb_debug_set_buffer(None)
-raw12 = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :12].astype(np.int64).reshape(-1, 12)
+raw_all = dbg.cpu().numpy().reshape(nblk, 16, 16)[:, :3, :12].astype(np.int64)
+if "--by-xcd" in sys.argv:   # wave slots of a persistent launch: block index b & 7 = XCD (observed round-robin placement)
+    for x in range(8):
+        r = raw_all[x::8].reshape(-1, 12); r = r[(r[:, 0] > 0) & (r[:, 9] > 0)]
+        if len(r):
+            print(f"  XCD {x}: {len(r):5d} tiles, mean tile {np.mean(r[:, 9] - r[:, 0]):8.0f} cycles, last tile ends at {(r[:, 11].max() - raw_all[..., 10][raw_all[..., 10] > 0].min()) / 100.0:6.1f} us")
+raw12 = raw_all.reshape(-1, 12)
 raw12 = raw12[(raw12[:, 0] > 0) & (raw12[:, 9] > 0)]
 raw = raw12[:, :10]
 t = raw.reshape(-1, 10)
