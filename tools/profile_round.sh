@@ -32,7 +32,7 @@ for p in ("f32", "f32x", "f16"):
     res["pmc_per_dispatch"][p] = vals
     for k in vals:
         if "k_render" in k and "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]:
-            name = "k_render_solo" if "solo" in k else "k_render_dense" if "dense" in k else "k_render_fused"
+            name = "k_render_solo" if "solo" in k else "k_render_dense" if "dense" in k else "k_render_flat" if "flat" in k else "k_render_fused"
             res["traffic_bytes"][f"{wl}:{name}:{p}"] = (2.0 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024.0   # KB -> bytes, read side doubled (gfx950)
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print("fused kernel HBM traffic per launch (bytes):", res["traffic_bytes"])

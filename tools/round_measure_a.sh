@@ -1,5 +1,7 @@
+#!/bin/bash
+# First half of a round's measurements: the driver-like and default bench lines, all workloads x precisions, phase / residency stamps.
 set -u
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r04m; mkdir -p $OUT; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r04}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; cd $ROOT
 echo "== driver-like (20 steps)"; timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_like_20_steps.json 2> $OUT/bench_driver_like.err
 echo "== default";                timeout -k 10 500 python3 bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "== all workloads";          BENCH_STEPS=300 timeout -k 10 900 bash tools/bench_all.sh > $OUT/bench_all_workloads.json 2> $OUT/bench_all.err
