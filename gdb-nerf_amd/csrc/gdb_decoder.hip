@@ -52,9 +52,11 @@ typedef unsigned U2 __attribute__((ext_vector_type(2)));
 #define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
 // ---- packed weights -------------------------------------------------------------------------------------------------
-// A convolution layer: [tile NT][chunk][tap 9][u 8][lane 64][2] floats; element e of lane (i, h) = W[32 tile + i][32 chunk + 4 u +
-// 2 h + e][tap], zero beyond the layer's channels.  (K-step 2u + e pairs the input channels 4u + e (half 0) and 4u + 2 + e
-// (half 1): a lane's two K-steps are two CONSECUTIVE channels, one 8-byte LDS read.)
+// A convolution layer: [tile NT][chunk][tap 9][u2 4][lane 64][4] floats; element e of lane (i, h) = W[32 tile + i][32 chunk + 4 u +
+// 2 h + (e & 1)][tap] with u = 2 u2 + (e >> 1), zero beyond the layer's channels.  (K-step 2u + e' pairs the input channels 4u + e'
+// (half 0) and 4u + 2 + e' (half 1): a lane's two K-steps are two CONSECUTIVE channels, one 8-byte LDS read; one 16-byte packet =
+// four K-steps, so a tap is FOUR vector loads per wave - as 8-byte packets the weight stream alone kept the texture addresser busy
+// half of a 64-channel layer's matrix time and all of a 32-channel layer's: 16 cycles per wave load whatever its width.)
 static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 9 * 8 * 64 * 2 * nt; }
 struct DecLayout {
     size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
@@ -91,29 +93,33 @@ static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
     for (int t = 0; t < nt; ++t)
         for (int ch = 0; ch < nchunk; ++ch)
             for (int tap = 0; tap < 9; ++tap)
-                for (int u = 0; u < 8; ++u)
+                for (int u2 = 0; u2 < 4; ++u2)
                     for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 2; ++e) {
-                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 4 * u + 2 * h + e;
+                        for (int e = 0; e < 4; ++e) {
+                            const int u = 2 * u2 + (e >> 1);
+                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 4 * u + 2 * h + (e & 1);
                             float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
-                            out[(((((size_t)t * nchunk + ch) * 9 + tap) * 8 + u) * 64 + l) * 2 + e] = v;
+                            out[(((((size_t)t * nchunk + ch) * 9 + tap) * 4 + u2) * 64 + l) * 4 + e] = v;
                         }
 }
 
 // A layer of at most 32 output channels for k_conv16 (v_mfma_f32_16x16x4_f32: 16 output rows x 16 pixels x 4 input channels per
-// instruction, the same FLOP rate as the 32x32x2 form): [chunk][tap 9][g 8][lane 64][2] floats; element mt of lane l =
-// W[16 mt + (l & 15)][32 chunk + 4 g + (l >> 4)][tap] - the lane supplies A[row l & 15][k = l >> 4] of output tile mt.  Same size as
-// pack_conv's one-tile form.
+// instruction, the same FLOP rate as the 32x32x2 form): [tile mt][chunk][tap 9][g4 2][lane 64][4] floats; element e of lane l =
+// W[16 mt + (l & 15)][32 chunk + 4 (4 g4 + e) + (l >> 4)][tap] - the lane supplies A[row l & 15][k = l >> 4] of output tile mt for
+// four consecutive k-groups: a tap of one tile is TWO 16-byte vector loads per wave.  A layer of <= 16 channels packs tile 0 only.
+// Never larger than pack_conv's one-tile form.
 static void pack_conv16(const float* w, int cout, int cin, float* out) {
-    const int nchunk = (cin + 31) / 32;
-    for (int ch = 0; ch < nchunk; ++ch)
-        for (int tap = 0; tap < 9; ++tap)
-            for (int g = 0; g < 8; ++g)
-                for (int l = 0; l < 64; ++l)
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int co = 16 * mt + (l & 15), ci = 32 * ch + 4 * g + (l >> 4);
-                        out[((((size_t)ch * 9 + tap) * 8 + g) * 64 + l) * 2 + mt] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
-                    }
+    const int nchunk = (cin + 31) / 32, nmt = (cout + 15) / 16;
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int g4 = 0; g4 < 2; ++g4)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = 16 * mt + (l & 15), ci = 32 * ch + 4 * (4 * g4 + e) + (l >> 4);
+                            out[(((((size_t)mt * nchunk + ch) * 9 + tap) * 2 + g4) * 64 + l) * 4 + e] =
+                                (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                        }
 }
 
 // The same layer as split-f16 A-operand fragments of v_mfma_f32_32x32x16_f16: [tile NT][16-channel chunk][tap 9][hi, lo][lane 64][8
@@ -232,9 +238,19 @@ struct ConvArgs {
 
 extern __shared__ float dsmem[];
 
+// Load through (wave-uniform base, 32-bit byte offset): the base stays in SGPRs and the offset is one VGPR instead of a 64-bit
+// per-lane address per load (ten registers of a staging plan's five slots, which is what spilled at five waves per SIMD).
+template <typename T>
+__device__ __forceinline__ T ldu(const void* __restrict__ base, unsigned byte_off) {
+    return *(const T*)((const char*)base + byte_off);
+}
+
 // NT = output tiles of the layer (1: 32 channels, 4 rows per workgroup; 2: 64 channels, 2 rows x 2 tiles per workgroup).
-template <int NT>
-__global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
+// VEC: the input rows allow 16-byte loads and the layer's channel count is a multiple of 4 (every layer but in_conv) - a template
+// parameter, not a run-time branch: as `if (a.vec)` each staging slot became its own basic block ending in s_waitcnt vmcnt(0), five
+// serial memory round trips at the top of every chunk instead of five loads in flight under the previous chunk's MFMAs.
+template <int NT, bool VEC>
+__global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
     constexpr int TR = 4 / NT;   // rows per workgroup
     float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -256,76 +272,80 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
     // MFMAs and stored to LDS after them — issued at the top of their own chunk they left every workgroup waiting out an L2 / HBM
     // round trip per chunk, which the 32-channel layers' 2.5 waves per SIMD could not cover (48 us for 22 us of MFMAs).
     constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    int soff[NSLOT];   // float offset of the slot's pixel inside the input (clamped into the image), channel group excluded
-    int loff[NSLOT];   // float offset of the slot in LDS, -1: no slot
+    unsigned soff[NSLOT];   // byte offset of the slot's pixel inside the input (clamped into the image), channel group excluded
     unsigned inimg = 0;
     const int g4 = 4 * (tid & 7);   // the slot's 4-channel group inside a chunk: (tid + 256 s) & 7 = tid & 7
+    const int loff0 = (tid >> 3) * DEC_CHS + g4;   // float offset of slot 0 in LDS; slot s lies 32 pixels further
+    constexpr int LAST = (TR + 2) * DEC_PX * 8 - 256 * (NSLOT - 1);   // threads that own a slot in the last round
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = tid + 256 * s;
         const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
         const int px = x0 - 1 + rx, py = y0 - 1 + ry;
         const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        loff[s] = slot ? p * DEC_CHS + g4 : -1;
         const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
         inimg |= (in ? 1u : 0u) << s;
-        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
+        soff[s] = 4u * (unsigned)(in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off);
     }
     const float* inb = a.in + img * a.in_stride;   // (a frame's input is < 2^31 floats: checked on the host)
-    const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2 + (size_t)lane * 2;
+    const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2;   // wave-uniform
+    const unsigned wlane = 16u * (unsigned)lane;
     const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
     F4 pre[NSLOT];
     auto fetch = [&](int ch) {
         const int ci = 32 * ch + g4;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            if (a.vec) pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
+            if (VEC) pre[s] = ldu<F4>(inb, soff[s] + 4u * (unsigned)(ci + 3 < a.cin ? ci : 0));
             else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
+                for (int k = 0; k < 4; ++k) pre[s][k] = ldu<float>(inb, soff[s] + 4u * (unsigned)min(ci + k, a.cin - 1));
             }
         }
     };
     // (Measured for the 64-channel layers too, although the chunk in flight costs them two of their six waves per SIMD: decoder
     // 0.804 -> 0.771 ms with the loads ahead in both, 0.780 in the 32-channel layers only.)
     fetch(0);
-    // weights: the next tap's 8 packets are loaded while the current tap's 16 MFMAs run (L2 latency under the matrix pipe)
-    F2 wn[8];
+    // weights: a tap = 4 packets = two halves of 8 MFMAs; the next half's 2 packets are loaded while the current half's MFMAs run (L2
+    // latency under the matrix pipe: 512 matrix cycles of this wave, five times that with its SIMD-mates).  A whole tap ahead costs 16
+    // more registers, which at five waves per SIMD (96) is a spill.
+    F4 wn[2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wn[u] = *(const F2*)(wbase + (size_t)u * 128);
+    for (int u = 0; u < 2; ++u) wn[u] = ldu<F4>(wbase, wlane + 1024u * u);
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();  // the previous chunk's reads are done
         // stage the rows + halo of this 32-channel chunk: zero outside the image (padding = 1) and beyond the layer's channels
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            if (loff[s] < 0) continue;
+            if (s == NSLOT - 1 && tid >= LAST) continue;
             const int ci = 32 * ch + g4;
             const bool in = (inimg >> s) & 1;
             F4 v = pre[s];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (in && (a.vec ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
-            F2* dst = (F2*)(lds + loff[s]);  // 8-byte aligned (DEC_CHS is even)
+            for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+            F2* dst = (F2*)(lds + loff0 + s * 32 * DEC_CHS);  // 8-byte aligned (DEC_CHS is even)
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
         if (ch + 1 < a.nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            F2 w[8];
+        for (int hp = 0; hp < 18; ++hp) {   // (tap, half)
+            const int tap = hp >> 1, dy = tap / 3, dx = tap % 3, u0 = 4 * (hp & 1);
+            F4 w[2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = wn[u];
-            {   // prefetch: next tap of this chunk, or tap 0 of the next chunk (the last prefetch of the layer reads the packed
-                // buffer's next layer / tail padding: in bounds by construction of dec_layout, never used)
-                const float* wnext = wbase + ((size_t)ch * 9 + tap + 1) * 8 * 128;
+            for (int u = 0; u < 2; ++u) w[u] = wn[u];
+            {   // prefetch: the next half of this chunk, or the first of the next chunk (the last prefetch of the layer reads the
+                // packed buffer's next layer / tail padding: in bounds by construction of dec_layout, never used)
+                const float* wnext = wbase + ((size_t)ch * 18 + hp + 1) * 4 * 128;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wn[u] = *(const F2*)(wnext + (size_t)u * 128);
+                for (int u = 0; u < 2; ++u) wn[u] = ldu<F4>(wnext, wlane + 1024u * u);
             }
+            __builtin_amdgcn_sched_barrier(0);   // the loads stay ahead of these MFMAs (left alone the scheduler sank each next to its use)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const F2 bv = *(const F2*)(brow + (size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * u);
-                acc = MFMA32(w[u][0], bv[0], acc);
-                acc = MFMA32(w[u][1], bv[1], acc);
+            for (int u = 0; u < 4; ++u) {
+                const F2 bv = *(const F2*)(brow + (size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * (u0 + u));
+                acc = MFMA32(w[u >> 1][2 * (u & 1)], bv[0], acc);
+                acc = MFMA32(w[u >> 1][2 * (u & 1) + 1], bv[1], acc);
             }
         }
     }
@@ -360,74 +380,83 @@ __global__ void __launch_bounds__(256) k_conv3x3(ConvArgs a) {
 // Layers of at most 32 output channels (conv1, conv2 of a dense block; the folded up stage with its 12) on v_mfma_f32_16x16x4_f32.
 // The 32x32x2 kernel above gives such a layer 2,560 equal waves for 1,024 SIMDs on a 256x320 map - half the SIMDs run three of them,
 // half two, and the layer takes three units of time for 2.5 units of work - and the 12-channel up stage wastes 20 of its 32 MFMA rows.
-// Here a wave is 16 pixels x MT tiles of 16 output channels (two accumulators of four registers), a workgroup 2 rows x 2 pixel
-// halves: 5,120 waves = five per SIMD, and the up stage (MT = 1) pays for 16 rows.  Staging is the 32x32x2 kernel's (rows + halo of a
-// 32-channel chunk in LDS, pixel stride 34 floats: lane l reads channel 4 g + (l >> 4) of pixel l & 15, 64 distinct banks); a B
-// operand is one ds_read_b32 and feeds MT MFMAs; weights stream from L2 as one float2 per lane and k-group (pack_conv16).
-template <int MT>
-__global__ void __launch_bounds__(256) k_conv16(ConvArgs a) {
+// Here a workgroup is 2 image rows x 32 pixels and a wave 16 pixels of it:
+//   NR = 2 (17..32 output channels): wave (pixel half, tile mt) renders BOTH rows of ONE 16-channel tile - the two rows share every
+//          weight packet, so the wave streams 18 KiB of weights per 32-channel chunk instead of the 36 KiB a (row, half) wave with both
+//          tiles needs (round 3's form: its weight loads alone, 72 per chunk and wave at 16 addresser cycles each, equalled the
+//          layer's matrix time);
+//   NR = 1 (<= 16 output channels):  wave (pixel half, row), tile 0.
+// Either way 5,120 equal waves on a 256x320 map = five per SIMD.  Staging is the 32x32x2 kernel's (rows + halo of a 32-channel chunk
+// in LDS, pixel stride 34 floats: lane l reads channel 4 g + (l >> 4) of pixel l & 15, 64 distinct banks); a B operand is one
+// ds_read_b32; weights stream from L2 as 16-byte packets = four k-groups (pack_conv16), the next tap's under the current tap's MFMAs.
+template <int NR, bool VEC>
+__global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
     constexpr int TR = 2;        // rows per workgroup
     float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, kq = lane >> 4;
-    const int wrow = wid >> 1, ph = wid & 1;   // this wave's row of the workgroup and 16-pixel half of the column
+    const int ph = wid & 1;                       // this wave's 16-pixel half of the column
+    const int mt = NR == 2 ? wid >> 1 : 0;        // its 16-channel output tile
+    const int wrow = NR == 2 ? 0 : wid >> 1;      // its first row of the workgroup
     const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
     const int x0 = bx * 32, y0 = by * TR;
-    F4 acc[MT];   // D layout: register r of lane l = output row 4 (l >> 4) + r of pixel l & 15
+    F4 acc[NR];   // D layout: register r of lane l = output row 4 (l >> 4) + r of pixel l & 15
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int r = 0; r < 4; ++r) {
+        const int co = 16 * mt + 4 * kq + r;
+        const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = 16 * mt + 4 * kq + r;
-            acc[mt][r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
-        }
+        for (int q = 0; q < NR; ++q) acc[q][r] = bv;
+    }
     const size_t img = (size_t)b * a.H * a.W;
     // staging plan: as k_conv3x3 (slots fixed per thread, branch-free loads one chunk ahead)
     constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    int soff[NSLOT], loff[NSLOT];
+    unsigned soff[NSLOT];
     unsigned inimg = 0;
     const int g4 = 4 * (tid & 7);
+    const int loff0 = (tid >> 3) * DEC_CHS + g4;
+    constexpr int LAST = (TR + 2) * DEC_PX * 8 - 256 * (NSLOT - 1);
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = tid + 256 * s;
         const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
         const int px = x0 - 1 + rx, py = y0 - 1 + ry;
         const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        loff[s] = slot ? p * DEC_CHS + g4 : -1;
         const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
         inimg |= (in ? 1u : 0u) << s;
-        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
+        soff[s] = 4u * (unsigned)(in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off);
     }
     const float* inb = a.in + img * a.in_stride;
-    const float* wbase = a.w + (size_t)lane * 2;
+    const float* wbase = a.w + (size_t)mt * a.nchunk * 9 * 2 * 64 * 4;   // wave-uniform
+    const unsigned wlane = 16u * (unsigned)lane;
     const float* brow = lds + (size_t)(wrow * DEC_PX + 16 * ph + pl) * DEC_CHS + kq;
     F4 pre[NSLOT];
     auto fetch = [&](int ch) {
         const int ci = 32 * ch + g4;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            if (a.vec) pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
+            if (VEC) pre[s] = ldu<F4>(inb, soff[s] + 4u * (unsigned)(ci + 3 < a.cin ? ci : 0));
             else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
+                for (int k = 0; k < 4; ++k) pre[s][k] = ldu<float>(inb, soff[s] + 4u * (unsigned)min(ci + k, a.cin - 1));
             }
         }
     };
     fetch(0);
-    F2 wn[8];   // the next tap's weights, loaded while the current tap's MFMAs run
+    F4 wn[2];   // the next tap's weights, loaded while the current tap's MFMAs run
 #pragma unroll
-    for (int g = 0; g < 8; ++g) wn[g] = *(const F2*)(wbase + (size_t)g * 128);
+    for (int g = 0; g < 2; ++g) wn[g] = ldu<F4>(wbase, wlane + 1024u * g);
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            if (loff[s] < 0) continue;
+            if (s == NSLOT - 1 && tid >= LAST) continue;
             const int ci = 32 * ch + g4;
             const bool in = (inimg >> s) & 1;
             F4 v = pre[s];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (in && (a.vec ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
-            F2* dst = (F2*)(lds + loff[s]);
+            for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+            F2* dst = (F2*)(lds + loff0 + s * 32 * DEC_CHS);
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
@@ -435,31 +464,35 @@ __global__ void __launch_bounds__(256) k_conv16(ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
-            F2 w[8];
+            F4 w[2];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) w[g] = wn[g];
-            {   // (the last prefetch of a layer reads the packed buffer's next layer / tail padding: in bounds, never used)
-                const float* wnext = wbase + ((size_t)ch * 9 + tap + 1) * 8 * 128;
+            for (int g = 0; g < 2; ++g) w[g] = wn[g];
+            {   // (the last prefetch of a tile reads the packed buffer's next tile / layer / tail padding: in bounds, never used)
+                const float* wnext = wbase + ((size_t)ch * 9 + tap + 1) * 2 * 256;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) wn[g] = *(const F2*)(wnext + (size_t)g * 128);
+                for (int g = 0; g < 2; ++g) wn[g] = ldu<F4>(wnext, wlane + 1024u * g);
             }
+            __builtin_amdgcn_sched_barrier(0);   // the loads stay ahead of this tap's MFMAs (left alone the scheduler sank each next to its use)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const float bv = brow[(size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * g];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][0], bv, acc[0], 0, 0, 0);
-                if (MT > 1) acc[MT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][1], bv, acc[MT - 1], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float bv = brow[(size_t)((dy + q) * DEC_PX + dx) * DEC_CHS + 4 * g];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g >> 2][g & 3], bv, acc[q], 0, 0, 0);
+                }
             }
         }
     }
-    // epilogue: lane (pl, kq) holds output channels 16 mt + 4 kq + (0..3) of pixel (y0 + wrow, x0 + 16 ph + pl)
-    const int x = x0 + 16 * ph + pl, y = y0 + wrow;
-    if (x >= a.W || y >= a.H) return;
-    const size_t pix = img + (size_t)y * a.W + x;
+    // epilogue: lane (pl, kq) holds output channels 16 mt + 4 kq + (0..3) of pixels (y0 + wrow + q, x0 + 16 ph + pl)
+    const int x = x0 + 16 * ph + pl;
+    const int co = 16 * mt + 4 * kq;
+    if (x >= a.W || co >= a.cout) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int co = 16 * mt + 4 * kq;
-        if (co >= a.cout) continue;
-        F4 v = acc[mt];
+    for (int q = 0; q < NR; ++q) {
+        const int y = y0 + wrow + q;
+        if (y >= a.H) continue;
+        const size_t pix = img + (size_t)y * a.W + x;
+        F4 v = acc[q];
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
             const int Ho = 2 * a.H, Wo = 2 * a.W;
@@ -714,14 +747,18 @@ __global__ void __launch_bounds__(256) k_se_apply(float* __restrict__ X, const f
 template <int NT>
 static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (size_t)(4 / NT + 2) * DEC_PX * DEC_CHS;
-    hipLaunchKernelGGL((k_conv3x3<NT>), dim3((unsigned)(a.B * a.tilesX * a.tilesY)), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY));
+    if (a.vec) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
-template <int MT>
+template <int NR>
 static hipError_t launch_conv16(const ConvArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
-    hipLaunchKernelGGL((k_conv16<MT>), dim3((unsigned)(a.B * a.tilesX * a.tilesY)), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY));
+    if (a.vec) hipLaunchKernelGGL((k_conv16<NR, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv16<NR, false>), grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -757,8 +794,8 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     if (ld_bundle_feat < Q) return gdb_fail(GDB_E_SHAPE, "bundle_feat row stride %d < %d channels", ld_bundle_feat, Q);
     const DecWs ws = dec_ws(B, H, W);
     if (ws_bytes < ws.total) return gdb_fail(GDB_E_WORKSPACE, "decoder workspace %zu B < required %zu B", ws_bytes, ws.total);
-    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_CS ? ld_bundle_feat : DEC_CS) >= ((size_t)1 << 31))
-        return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging offsets");
+    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_CS ? ld_bundle_feat : DEC_CS) >= ((size_t)1 << 30))
+        return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging byte offsets");
     const DecLayout L = dec_layout(num_layers);
     hipStream_t st = (hipStream_t)stream_;
     float* X = (float*)((char*)d_ws + ws.X); float* S = (float*)((char*)d_ws + ws.S); float* T = (float*)((char*)d_ws + ws.T);

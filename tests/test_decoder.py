@@ -21,37 +21,42 @@ def _dec_state(f7):
 
 
 def _unpack_conv(packed, cout, cin, nt):
-    """Inverse of pack_conv (gdb_decoder.hip): [tile][chunk][tap][u][lane][e] -> (cout, cin, 3, 3)."""
+    """Inverse of pack_conv (gdb_decoder.hip): [tile][chunk][tap][u2 4][lane][e 4] -> (cout, cin, 3, 3); element e of lane (i, h) is
+    input channel 32 chunk + 4 u + 2 h + (e & 1) with u = 2 u2 + (e >> 1)."""
     nchunk = (cin + 31) // 32
-    a = packed[:nt * nchunk * 9 * 8 * 64 * 2].reshape(nt, nchunk, 9, 8, 64, 2)
+    a = packed[:nt * nchunk * 9 * 4 * 64 * 4].reshape(nt, nchunk, 9, 4, 64, 4)
     w = np.zeros((cout, cin, 9), np.float32)
     for t in range(nt):
         for ch in range(nchunk):
-            for u in range(8):
+            for u2 in range(4):
                 for l in range(64):
                     i, h = l & 31, l >> 5
-                    for e in range(2):
-                        co, ci = 32 * t + i, 32 * ch + 4 * u + 2 * h + e
+                    for e in range(4):
+                        co, ci = 32 * t + i, 32 * ch + 4 * (2 * u2 + (e >> 1)) + 2 * h + (e & 1)
                         if co < cout and ci < cin:
-                            w[co, ci, :] = a[t, ch, :, u, l, e]
+                            w[co, ci, :] = a[t, ch, :, u2, l, e]
+                        else:
+                            assert np.all(a[t, ch, :, u2, l, e] == 0)
     return w.reshape(cout, cin, 3, 3)
 
 
 def _unpack_conv16(packed, cout, cin):
-    """Inverse of pack_conv16 (layers of <= 32 output channels, v_mfma_f32_16x16x4_f32 operand order): [chunk][tap][g][lane][mt]
-    -> (cout, cin, 3, 3); element mt of lane l = W[16 mt + (l & 15)][32 chunk + 4 g + (l >> 4)][tap]."""
-    nchunk = (cin + 31) // 32
-    a = packed[:nchunk * 9 * 8 * 64 * 2].reshape(nchunk, 9, 8, 64, 2)
+    """Inverse of pack_conv16 (layers of <= 32 output channels, v_mfma_f32_16x16x4_f32 operand order): [tile mt][chunk][tap][g4 2]
+    [lane][e 4] -> (cout, cin, 3, 3); element e of lane l = W[16 mt + (l & 15)][32 chunk + 4 (4 g4 + e) + (l >> 4)][tap]; a layer of
+    <= 16 channels packs tile 0 only."""
+    nchunk, nmt = (cin + 31) // 32, (cout + 15) // 16
+    a = packed[:nmt * nchunk * 9 * 2 * 64 * 4].reshape(nmt, nchunk, 9, 2, 64, 4)
     w = np.zeros((cout, cin, 9), np.float32)
-    for ch in range(nchunk):
-        for g in range(8):
-            for l in range(64):
-                for mt in range(2):
-                    co, ci = 16 * mt + (l & 15), 32 * ch + 4 * g + (l >> 4)
-                    if co < cout and ci < cin:
-                        w[co, ci, :] = a[ch, :, g, l, mt]
-                    else:
-                        assert np.all(a[ch, :, g, l, mt] == 0)
+    for mt in range(nmt):
+        for ch in range(nchunk):
+            for g4 in range(2):
+                for l in range(64):
+                    for e in range(4):
+                        co, ci = 16 * mt + (l & 15), 32 * ch + 4 * (4 * g4 + e) + (l >> 4)
+                        if co < cout and ci < cin:
+                            w[co, ci, :] = a[mt, ch, :, g4, l, e]
+                        else:
+                            assert np.all(a[mt, ch, :, g4, l, e] == 0)
     return w.reshape(cout, cin, 3, 3)
 
 
