@@ -204,17 +204,25 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
 }
 
 // ---- workspace -------------------------------------------------------------------------------------------------------
-struct DecWs { size_t X, S, T, part, gate, total; int nblk; };
+// Activations are (pixels, 64) buffers: P[b] = the input x of dense block b (P[0] = in_conv's output, kept to the end as the decoder's
+// global residual), Y = [x1 | x2] of the block in flight, T = conv3's output; the dense block's torch.cat([x, x1, x2]) is "chunks 0-1
+// from P[b], chunks 2-3 from Y".  part = per-(row, 32-pixel segment) channel sums of T (written by conv3's epilogue), part2 = their
+// sums per group of DEC_SEG segments, gate = the block's 64 gates per batch item, count = one arrival counter per batch item.
+#define DEC_SEG 64   // segments per workgroup of k_se_gate's first stage
+struct DecWs { size_t P[3], Y, T, part, part2, gate, count, total; int nseg, ngrp; };
 static DecWs dec_ws(int B, int H, int W) {
     DecWs w{};
     const size_t n = (size_t)B * H * W;
-    w.nblk = (int)(((size_t)H * W + DEC_RED - 1) / DEC_RED);  // pixels per partial-sum block
+    w.nseg = H * ((W + 31) / 32);
+    w.ngrp = (w.nseg + DEC_SEG - 1) / DEC_SEG;
     size_t o = 0;
-    w.X = o; o = align_up(o + sizeof(float) * n * DEC_CS, 256);
-    w.S = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256);
+    for (int i = 0; i < 3; ++i) { w.P[i] = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256); }
+    w.Y = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256);
     w.T = o; o = align_up(o + sizeof(float) * n * DEC_NF, 256);
-    w.part = o; o = align_up(o + sizeof(float) * (size_t)B * w.nblk * DEC_NF, 256);
+    w.part = o; o = align_up(o + sizeof(float) * (size_t)B * w.nseg * DEC_NF, 256);
+    w.part2 = o; o = align_up(o + sizeof(float) * (size_t)B * w.ngrp * DEC_NF, 256);
     w.gate = o; o = align_up(o + sizeof(float) * (size_t)B * DEC_NF, 256);
+    w.count = o; o = align_up(o + sizeof(unsigned) * (size_t)B, 256);
     w.total = o;
     return w;
 }
@@ -229,10 +237,15 @@ extern "C" int gdb_decoder_workspace_bytes(const GdbConfig* cfg, const GdbFrame*
 // ---- 3x3 convolution ----------------------------------------------------------------------------------------------------
 struct ConvArgs {
     const float* in; int in_stride, in_off, cin, nchunk, vec;  // vec: the input rows allow 16-byte loads
+    const float* in2; int split;    // 32-channel chunks >= split come from in2 (row stride in_stride, channel 32 (chunk - split))
     const float* w; const float* bias;
     float* out; int out_stride, out_off, cout, relu;
-    float* out2; int out2_stride;   // optional second copy of the output (channels 0..cout-1)
     float* rgb;                     // folded up stage: (B,3,2H,2W) NCHW, channel c = 3 s + o of sub-pixel s = dy*2 + dx
+    // squeeze-excitation folded into the consumer (FUSE kernels; decoder_rdn.py:40,78): the staged input is x = in + fT * gate (+ fS),
+    // all (pixels, 64); the workgroup's own pixels of x are also written to fX (the next block's P) when fX is set
+    const float* fT; const float* fgate; const float* fS; float* fX;
+    float* se_part;                 // SEP kernels (conv3): channel sums of the output per (row, 32-pixel segment)
+    unsigned* zero;                 // in_conv: the arrival counters of k_se_gate, cleared for this decode
     int B, H, W, tilesX, tilesY;
 };
 
@@ -245,11 +258,103 @@ __device__ __forceinline__ T ldu(const void* __restrict__ base, unsigned byte_of
     return *(const T*)((const char*)base + byte_off);
 }
 
-// NT = output tiles of the layer (1: 32 channels, 4 rows per workgroup; 2: 64 channels, 2 rows x 2 tiles per workgroup).
-// VEC: the input rows allow 16-byte loads and the layer's channel count is a multiple of 4 (every layer but in_conv) - a template
-// parameter, not a run-time branch: as `if (a.vec)` each staging slot became its own basic block ending in s_waitcnt vmcnt(0), five
-// serial memory round trips at the top of every chunk instead of five loads in flight under the previous chunk's MFMAs.
-template <int NT, bool VEC>
+// Staging plan of a 256-thread workgroup: rows y0-1 .. y0+TR of the 34-pixel column x0-1 .. x0+32, one chunk of 4 NG input channels
+// at a time.  The (pixel, 4-channel group) slots a thread fills are the same for every chunk, so their source offsets are computed
+// once (the divisions by 34 are not cheap, and VALU cycles are matrix cycles on the fp32 datapath).  The loads are branch-free (a slot
+// outside the image or beyond the layer's channels loads a valid address and is zeroed in value()) and run one chunk ahead: a chunk's
+// global loads are issued before the previous chunk's MFMAs and consumed after them.
+//   VEC:  the input rows allow 16-byte loads and the channel count is a multiple of 4 (every layer but in_conv) - a template parameter,
+//         not a run-time branch: as `if (a.vec)` each slot became its own basic block ending in s_waitcnt vmcnt(0), five serial memory
+//         round trips at the top of every chunk instead of five loads in flight under the previous chunk's MFMAs.
+//   FUSE: the squeeze-excitation apply of the PREVIOUS block happens here (x = in + fT * gate, + fS for the decoder's global residual,
+//         rounded exactly as the separate element-wise pass rounded them): the pass itself - 63 MB of traffic, 11 us per block at the
+//         DTU size - is gone, and so is the second copy of in_conv's output it needed.
+template <int TR, int NG, bool VEC, bool FUSE>
+struct Stager {
+    static constexpr int CH = 4 * NG;                       // channels per chunk
+    static constexpr int NPG = (TR + 2) * DEC_PX * NG;      // (pixel, group) slots of a chunk
+    static constexpr int NSLOT = (NPG + 255) / 256;
+    static constexpr int LAST = NPG - 256 * (NSLOT - 1);    // threads that own a slot in the last round
+    static constexpr int SH = NG == 8 ? 3 : 2;
+    unsigned soff[NSLOT];   // byte offset of the slot's pixel inside the input (clamped into the image), channel group excluded
+    unsigned inimg, inner;  // bit s: the slot's pixel lies inside the image / is one of the workgroup's own output pixels
+    int g4;                 // the slot's 4-channel group inside a chunk: (tid + 256 s) & (NG - 1) = tid & (NG - 1)
+    F4 pre[NSLOT], preT[FUSE ? NSLOT : 1], gate4;
+    const float* inb; const float* in2b; const float* fTb; const float* fSb; float* fXb;
+
+    __device__ __forceinline__ void init(const ConvArgs& a, int tid, int b, int x0, int y0) {
+        const size_t img = (size_t)b * a.H * a.W;
+        inb = a.in + img * a.in_stride;   // (a frame's input is < 2^30 floats: checked on the host)
+        in2b = a.in2 ? a.in2 + img * a.in_stride : inb;
+        if (FUSE) {
+            fTb = a.fT + img * DEC_NF; fSb = a.fS ? a.fS + img * DEC_NF : nullptr; fXb = a.fX ? a.fX + img * DEC_NF : nullptr;
+            gate4 = F4{0.f, 0.f, 0.f, 0.f};
+        }
+        g4 = 4 * (tid & (NG - 1));
+        inimg = 0; inner = 0;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int idx = tid + 256 * s;
+            const int p = idx >> SH, rx = p % DEC_PX, ry = p / DEC_PX;
+            const int px = x0 - 1 + rx, py = y0 - 1 + ry;
+            const bool slot = idx < NPG;
+            const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
+            inimg |= (in ? 1u : 0u) << s;
+            inner |= ((in && rx >= 1 && rx <= 32 && ry >= 1 && ry <= TR) ? 1u : 0u) << s;
+            soff[s] = 4u * (unsigned)(in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off);
+        }
+    }
+    __device__ __forceinline__ bool has(int s, int tid) const { return s < NSLOT - 1 || tid < LAST; }
+    // issue the loads of chunk ch (wave-uniform)
+    __device__ __forceinline__ void fetch(const ConvArgs& a, int b, int ch) {
+        const int split = a.split * (8 / NG);
+        const float* src = ch < split ? inb : in2b;
+        const int cl = CH * (ch < split ? ch : ch - split) + g4, ci = CH * ch + g4;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (VEC) pre[s] = ldu<F4>(src, soff[s] + 4u * (unsigned)(ci + 3 < a.cin ? cl : 0));
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre[s][k] = ldu<float>(src, soff[s] + 4u * (unsigned)min(cl + k, a.cin - 1));
+            }
+            if (FUSE) preT[s] = ldu<F4>(fTb, soff[s] + 4u * (unsigned)cl);
+        }
+        if (FUSE) gate4 = *(const F4*)(a.fgate + (size_t)b * DEC_NF + cl);
+    }
+    // the value of slot s of chunk ch as it is staged: zero outside the image (padding = 1) and beyond the layer's channels
+    __device__ __forceinline__ F4 value(const ConvArgs& a, int s, int ch) {
+        const int ci = CH * ch + g4;
+        const bool in = (inimg >> s) & 1;
+        F4 v = pre[s];
+        if (FUSE) {
+            const F4 tg = preT[s] * gate4;
+            v = v + tg;
+            if (fSb) v = v + ldu<F4>(fSb, soff[s] + 4u * (unsigned)ci);
+            if (fXb && ((inner >> s) & 1)) *(F4*)((char*)fXb + soff[s] + 4u * (unsigned)ci) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+        return v;
+    }
+};
+
+// Sum of v over the 32 lanes of the caller's half of the wave (fixed tree: deterministic), valid in every lane.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+// NT = output tiles of the layer (2: 64 channels, 2 rows x 2 tiles per workgroup).  One wave = one image-row segment of 32 pixels x one
+// tile of 32 output channels (one accumulator).  SEP: the epilogue also leaves the segment's per-channel sums of the output for the
+// squeeze-excitation mean (decoder_rdn.py:17-21) - a cross-lane tree on registers the wave holds anyway, instead of a pass over T.
+template <int NT, bool VEC, bool SEP>
 __global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
     constexpr int TR = 4 / NT;   // rows per workgroup
     float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
@@ -258,54 +363,22 @@ __global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
     const int t = wid % NT, wrow = wid / NT;   // this wave's output tile and row of the workgroup
     const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
     const int x0 = bx * 32, y0 = by * TR;
+    if (a.zero && blockIdx.x == 0 && tid < a.B) a.zero[tid] = 0u;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
         acc[r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
-    const size_t img = (size_t)b * a.H * a.W;
-    // staging plan of this thread: the (pixel, 4-channel group) slots it fills are the same for every chunk, so their source
-    // offsets and LDS addresses are computed once (the divisions by 34 are not cheap, and VALU cycles are matrix cycles on the
-    // fp32 datapath).  The loads are branch-free (a slot outside the image or beyond the layer's channels loads a valid address
-    // and is zeroed when it is stored) and run one chunk ahead: a chunk's global loads are issued before the previous chunk's
-    // MFMAs and stored to LDS after them — issued at the top of their own chunk they left every workgroup waiting out an L2 / HBM
-    // round trip per chunk, which the 32-channel layers' 2.5 waves per SIMD could not cover (48 us for 22 us of MFMAs).
-    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    unsigned soff[NSLOT];   // byte offset of the slot's pixel inside the input (clamped into the image), channel group excluded
-    unsigned inimg = 0;
-    const int g4 = 4 * (tid & 7);   // the slot's 4-channel group inside a chunk: (tid + 256 s) & 7 = tid & 7
-    const int loff0 = (tid >> 3) * DEC_CHS + g4;   // float offset of slot 0 in LDS; slot s lies 32 pixels further
-    constexpr int LAST = (TR + 2) * DEC_PX * 8 - 256 * (NSLOT - 1);   // threads that own a slot in the last round
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const int idx = tid + 256 * s;
-        const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
-        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
-        const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
-        inimg |= (in ? 1u : 0u) << s;
-        soff[s] = 4u * (unsigned)(in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off);
-    }
-    const float* inb = a.in + img * a.in_stride;   // (a frame's input is < 2^31 floats: checked on the host)
+    Stager<TR, 8, VEC, false> st;
+    st.init(a, tid, b, x0, y0);
+    const int loff0 = (tid >> 3) * DEC_CHS + st.g4;   // float offset of slot 0 in LDS; slot s lies 32 pixels further
     const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2;   // wave-uniform
     const unsigned wlane = 16u * (unsigned)lane;
     const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
-    F4 pre[NSLOT];
-    auto fetch = [&](int ch) {
-        const int ci = 32 * ch + g4;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (VEC) pre[s] = ldu<F4>(inb, soff[s] + 4u * (unsigned)(ci + 3 < a.cin ? ci : 0));
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pre[s][k] = ldu<float>(inb, soff[s] + 4u * (unsigned)min(ci + k, a.cin - 1));
-            }
-        }
-    };
-    // (Measured for the 64-channel layers too, although the chunk in flight costs them two of their six waves per SIMD: decoder
-    // 0.804 -> 0.771 ms with the loads ahead in both, 0.780 in the 32-channel layers only.)
-    fetch(0);
+    // (Measured for the 64-channel layers too, although the chunk in flight costs registers: decoder 0.804 -> 0.771 ms with the loads
+    // ahead in both, 0.780 in the 32-channel layers only.)
+    st.fetch(a, b, 0);
     // weights: a tap = 4 packets = two halves of 8 MFMAs; the next half's 2 packets are loaded while the current half's MFMAs run (L2
     // latency under the matrix pipe: 512 matrix cycles of this wave, five times that with its SIMD-mates).  A whole tap ahead costs 16
     // more registers, which at five waves per SIMD (96) is a spill.
@@ -314,20 +387,15 @@ __global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
     for (int u = 0; u < 2; ++u) wn[u] = ldu<F4>(wbase, wlane + 1024u * u);
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();  // the previous chunk's reads are done
-        // stage the rows + halo of this 32-channel chunk: zero outside the image (padding = 1) and beyond the layer's channels
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (s == NSLOT - 1 && tid >= LAST) continue;
-            const int ci = 32 * ch + g4;
-            const bool in = (inimg >> s) & 1;
-            F4 v = pre[s];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+        for (int s = 0; s < st.NSLOT; ++s) {
+            if (!st.has(s, tid)) continue;
+            const F4 v = st.value(a, s, ch);
             F2* dst = (F2*)(lds + loff0 + s * 32 * DEC_CHS);  // 8-byte aligned (DEC_CHS is even)
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
-        if (ch + 1 < a.nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
+        if (ch + 1 < a.nchunk) st.fetch(a, b, ch + 1);   // flies under this chunk's MFMAs
 #pragma unroll
         for (int hp = 0; hp < 18; ++hp) {   // (tap, half)
             const int tap = hp >> 1, dy = tap / 3, dx = tap % 3, u0 = 4 * (hp & 1);
@@ -351,28 +419,26 @@ __global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
     }
     // epilogue: lane (j, h) holds output channels 32 t + 8 g + 4 h + (0..3) of pixel (y, x0 + j)
     const int x = x0 + j, y = y0 + wrow;
-    if (x >= a.W || y >= a.H) return;
-    const size_t pix = img + (size_t)y * a.W + x;
+    const bool valid = x < a.W && y < a.H;
+    if (SEP && y < a.H) {   // (wave-uniform) the segment's channel sums: part[b][y * tilesX + bx][64]
+        float* dst = a.se_part + (((size_t)b * a.H + y) * a.tilesX + bx) * DEC_NF + 32 * t + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            F4 sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = half_wave_sum(valid ? acc[4 * g + k] : 0.f);
+            if (j == 0) *(F4*)(dst + 8 * g) = sum;
+        }
+    }
+    if (!valid) return;
+    const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co = 32 * t + 8 * g + 4 * h;
         if (co >= a.cout) continue;
         F4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
-            const int Ho = 2 * a.H, Wo = 2 * a.W;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = co + k;
-                if (c < 12) {
-                    const int s = c / 3, o = c - 3 * s;
-                    a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (s >> 1)) * Wo + 2 * x + (s & 1)] = v[k];
-                }
-            }
-        } else {
-            *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;   // all buffers: strides and offsets multiples of 4
-            if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
-        }
+        *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;   // all buffers: strides and offsets multiples of 4
     }
 }
 
@@ -389,7 +455,7 @@ __global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
 // Either way 5,120 equal waves on a 256x320 map = five per SIMD.  Staging is the 32x32x2 kernel's (rows + halo of a 32-channel chunk
 // in LDS, pixel stride 34 floats: lane l reads channel 4 g + (l >> 4) of pixel l & 15, 64 distinct banks); a B operand is one
 // ds_read_b32; weights stream from L2 as 16-byte packets = four k-groups (pack_conv16), the next tap's under the current tap's MFMAs.
-template <int NR, bool VEC>
+template <int NR, bool VEC, bool FUSE>
 __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
     constexpr int TR = 2;        // rows per workgroup
     float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
@@ -408,59 +474,27 @@ __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < NR; ++q) acc[q][r] = bv;
     }
-    const size_t img = (size_t)b * a.H * a.W;
-    // staging plan: as k_conv3x3 (slots fixed per thread, branch-free loads one chunk ahead)
-    constexpr int NSLOT = ((TR + 2) * DEC_PX * 8 + 255) / 256;
-    unsigned soff[NSLOT];
-    unsigned inimg = 0;
-    const int g4 = 4 * (tid & 7);
-    const int loff0 = (tid >> 3) * DEC_CHS + g4;
-    constexpr int LAST = (TR + 2) * DEC_PX * 8 - 256 * (NSLOT - 1);
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const int idx = tid + 256 * s;
-        const int p = idx >> 3, rx = p % DEC_PX, ry = p / DEC_PX;
-        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
-        const bool slot = idx < (TR + 2) * DEC_PX * 8;
-        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
-        inimg |= (in ? 1u : 0u) << s;
-        soff[s] = 4u * (unsigned)(in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off);
-    }
-    const float* inb = a.in + img * a.in_stride;
+    Stager<TR, 8, VEC, FUSE> st;
+    st.init(a, tid, b, x0, y0);
+    const int loff0 = (tid >> 3) * DEC_CHS + st.g4;
     const float* wbase = a.w + (size_t)mt * a.nchunk * 9 * 2 * 64 * 4;   // wave-uniform
     const unsigned wlane = 16u * (unsigned)lane;
     const float* brow = lds + (size_t)(wrow * DEC_PX + 16 * ph + pl) * DEC_CHS + kq;
-    F4 pre[NSLOT];
-    auto fetch = [&](int ch) {
-        const int ci = 32 * ch + g4;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (VEC) pre[s] = ldu<F4>(inb, soff[s] + 4u * (unsigned)(ci + 3 < a.cin ? ci : 0));
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pre[s][k] = ldu<float>(inb, soff[s] + 4u * (unsigned)min(ci + k, a.cin - 1));
-            }
-        }
-    };
-    fetch(0);
+    st.fetch(a, b, 0);
     F4 wn[2];   // the next tap's weights, loaded while the current tap's MFMAs run
 #pragma unroll
     for (int g = 0; g < 2; ++g) wn[g] = ldu<F4>(wbase, wlane + 1024u * g);
     for (int ch = 0; ch < a.nchunk; ++ch) {
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (s == NSLOT - 1 && tid >= LAST) continue;
-            const int ci = 32 * ch + g4;
-            const bool in = (inimg >> s) & 1;
-            F4 v = pre[s];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
+        for (int s = 0; s < st.NSLOT; ++s) {
+            if (!st.has(s, tid)) continue;
+            const F4 v = st.value(a, s, ch);
             F2* dst = (F2*)(lds + loff0 + s * 32 * DEC_CHS);
             dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
         }
         __syncthreads();
-        if (ch + 1 < a.nchunk) fetch(ch + 1);
+        if (ch + 1 < a.nchunk) st.fetch(a, b, ch + 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -491,7 +525,7 @@ __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
     for (int q = 0; q < NR; ++q) {
         const int y = y0 + wrow + q;
         if (y >= a.H) continue;
-        const size_t pix = img + (size_t)y * a.W + x;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
         F4 v = acc[q];
         if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
@@ -506,7 +540,6 @@ __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
             }
         } else {
             *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
-            if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
         }
     }
 }
@@ -528,11 +561,8 @@ constexpr int DECX_ROWS = 1;   // image rows per wave
 #ifndef DECX_PF
 #define DECX_PF 1              // taps of LDS operand reads in flight ahead of the MFMAs (1, 2, 3 measured the same)
 #endif
-// VEC: the input rows allow 16-byte loads and the layer's channel count is a multiple of 4 (every layer but in_conv, which reads
-// the 39- / 41-float bundle rows at channel 12).  The staging loads are branch-free — a slot outside the image or beyond the
-// layer's channels loads a valid address and is zeroed when it is converted — so a chunk's loads issue back to back (as
-// predicated branches each slot was its own basic block with its own vmcnt(0)).
-template <bool VEC>
+// Staging plan, VEC, FUSE: Stager<> above (16-channel chunks, four groups per pixel); SEP as in k_conv3x3.
+template <bool VEC, bool FUSE, bool SEP>
 __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
     constexpr int R = DECX_ROWS, TR = 4 * R;
     constexpr int PIXD = (TR + 2) * DEC_PX * DECX_PXD;   // dwords of the pixel image
@@ -548,6 +578,7 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
     const int t = blk % nt; blk /= nt;
     const int bx = blk % a.tilesX, by = (blk / a.tilesX) % a.tilesY, b = blk / (a.tilesX * a.tilesY);
     const int x0 = bx * 32, y0 = by * TR;
+    if (a.zero && blockIdx.x == 0 && tid < a.B) a.zero[tid] = 0u;
     f32x16 acc[R];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -556,51 +587,16 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q][r] = bv;
     }
-    const size_t img = (size_t)b * a.H * a.W;
-    constexpr int NPIX = (TR + 2) * DEC_PX * 4;          // (pixel, 4-channel group) slots of a chunk
-    constexpr int NSLOT = (NPIX + 255) / 256;
+    Stager<TR, 4, VEC, FUSE> st;
+    st.init(a, tid, b, x0, y0);
+    const int loff0 = (tid >> 2) * DECX_PXD + (st.g4 >> 1);   // dword offset of slot 0's hi halves in LDS (lo halves 8 dwords further); slot s: 64 pixels on
     constexpr int NW = (WFRAG + 255) / 256;
-    int soff[NSLOT];       // float offset of the slot's pixel inside the input (clamped into the image), channel group excluded
-    int loff[NSLOT];       // dword offset of the slot's hi halves in LDS (lo halves 8 dwords further)
-    unsigned inimg = 0;    // bit s: the slot exists and its pixel lies inside the image
-    const int g4 = 4 * (tid & 3);   // the slot's 4-channel group inside a chunk: (tid + 256 s) & 3 = tid & 3
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const int idx = tid + 256 * s;
-        const int p = idx >> 2, rx = p % DEC_PX, ry = p / DEC_PX;
-        const int px = x0 - 1 + rx, py = y0 - 1 + ry;
-        const bool slot = idx < NPIX;
-        loff[s] = slot ? p * DECX_PXD + (g4 >> 1) : -1;
-        const bool in = slot && px >= 0 && px < a.W && py >= 0 && py < a.H;
-        inimg |= (in ? 1u : 0u) << s;
-        soff[s] = in ? (int)(((size_t)py * a.W + px) * a.in_stride + a.in_off) : a.in_off;
-    }
-    const float* inb = a.in + img * a.in_stride;
     const half8* wsrc = (const half8*)a.w + (size_t)t * nchunk * WFRAG;
-    F4 pre[NSLOT];
     half8 wpre[NW];
     auto fetch = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) wpre[k] = wsrc[(size_t)ch * WFRAG + min(tid + 256 * k, WFRAG - 1)];
-        const int ci = 16 * ch + g4;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (VEC) {
-                pre[s] = *(const F4*)(inb + soff[s] + (ci + 3 < a.cin ? ci : 0));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pre[s][k] = inb[soff[s] + min(ci + k, a.cin - 1)];
-            }
-        }
-    };
-    // zero what the branch-free loads should not have brought: pixels outside the image, channels beyond the layer's
-    auto masked = [&](int s, int ch) {
-        const int ci = 16 * ch + g4;
-        F4 v = pre[s];
-        const bool in = (inimg >> s) & 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (in && (VEC ? ci + 3 : ci + k) < a.cin) ? v[k] : 0.f;
-        return v;
+        st.fetch(a, b, ch);
     };
     fetch(0);
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -609,16 +605,17 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
         for (int k = 0; k < NW; ++k)
             if (tid + 256 * k < WFRAG) *(half8*)(wl + (size_t)(tid + 256 * k) * 4) = wpre[k];
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (loff[s] < 0) continue;
-            const F4 v = masked(s, ch);
+        for (int s = 0; s < st.NSLOT; ++s) {
+            if (!st.has(s, tid)) continue;
+            const F4 v = st.value(a, s, ch);
+            unsigned* dst = lds + loff0 + s * 64 * DECX_PXD;
             const half2v h01 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
             const half2v h23 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
             const U2 hi = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
             const U2 lo = {__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01.x, v[1] - (float)h01.y)),
                            __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23.x, v[3] - (float)h23.y))};
-            *(U2*)(lds + loff[s]) = hi;
-            *(U2*)(lds + loff[s] + 8) = lo;
+            *(U2*)dst = hi;
+            *(U2*)(dst + 8) = lo;
         }
         __syncthreads();
         if (ch + 1 < nchunk) fetch(ch + 1);   // flies under this chunk's MFMAs
@@ -652,12 +649,23 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
         }
     }
     const int x = x0 + j;
-    if (x >= a.W) return;
 #pragma unroll
     for (int q = 0; q < R; ++q) {
         const int y = y0 + wrow0 + q;
-        if (y >= a.H) continue;
-        const size_t pix = img + (size_t)y * a.W + x;
+        if (y >= a.H) continue;   // (wave-uniform)
+        const bool valid = x < a.W;
+        if (SEP) {   // the segment's channel sums: part[b][y * tilesX + bx][64]
+            float* dst = a.se_part + (((size_t)b * a.H + y) * a.tilesX + bx) * DEC_NF + 32 * t + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                F4 sum;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum[k] = half_wave_sum(valid ? acc[q][4 * g + k] : 0.f);
+                if (j == 0) *(F4*)(dst + 8 * g) = sum;
+            }
+        }
+        if (!valid) continue;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = 32 * t + 8 * g + 4 * h;
@@ -676,46 +684,47 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
                 }
             } else {
                 *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
-                if (a.out2) *(F4*)(a.out2 + pix * a.out2_stride + co) = v;
             }
         }
     }
 }
 
 // ---- squeeze-excitation ------------------------------------------------------------------------------------------------
-// partial[b][blk][c] = sum over the block's DEC_RED pixels of T[.][c]; fixed order inside a block (16 pixel lanes per float4 of
-// channels, each in pixel order, then a fixed tree over the lanes), fixed order over blocks in k_se_gate: bit-reproducible.
-__global__ void __launch_bounds__(256) k_chan_partial(const float* __restrict__ T, int HW, int nblk, float* __restrict__ part) {
-    __shared__ F4 red[256];
-    const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
-    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int p0 = blk * DEC_RED, p1 = min(HW, p0 + DEC_RED);
-    F4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + pl; p < p1; p += 16) s = s + *(const F4*)(T + ((size_t)b * HW + p) * DEC_NF + 4 * c4);
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 8; st >= 1; st >>= 1) {
-        if (pl < st) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 16 * st];
-        __syncthreads();
-    }
-    if (pl == 0) *(F4*)(part + ((size_t)b * nblk + blk) * DEC_NF + 4 * c4) = red[c4];
-}
-// gate[b][c] = sigmoid(W2 relu(W1 mean))   decoder_rdn.py:17-21.  1024 threads: 16 groups x 64 channels sum the partials
-// (group g takes blocks g, g + 16, ...), then a fixed tree over the groups.
-__global__ void __launch_bounds__(1024) k_se_gate(const float* __restrict__ part, int nblk, float inv_hw, const float* __restrict__ w1,
-                                                  const float* __restrict__ w2, float* __restrict__ gate) {
-    __shared__ float red[1024];
+// gate[b][c] = sigmoid(W2 relu(W1 mean_c))   decoder_rdn.py:17-21, from the per-segment channel sums conv3's epilogue left in `part`
+// ([b][segment][64]).  One launch, two stages: a workgroup sums DEC_SEG segments (4 thread groups x 64 channels, each group its
+// segments in order, then a fixed tree over the groups) into part2[b][group]; the workgroup that arrives LAST at the batch item's
+// counter (release / acquire fences around a device-scope atomic) sums the groups in index order and runs the two tiny linears.  Every
+// sum has a fixed shape whatever the arrival order: bit-reproducible.  The counter is left at zero for the next block.
+__global__ void __launch_bounds__(256) k_se_gate(const float* __restrict__ part, int nseg, int ngrp, float inv_hw, const float* __restrict__ w1,
+                                                 const float* __restrict__ w2, float* __restrict__ part2, unsigned* __restrict__ count,
+                                                 float* __restrict__ gate) {
+    __shared__ float red[256];
     __shared__ float mean[DEC_NF], hid[DEC_SE_R];
-    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ unsigned ticket;
+    const int b = blockIdx.x / ngrp, grp = blockIdx.x % ngrp;
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const float* src = part + (size_t)b * nseg * DEC_NF;
+    const int s0 = grp * DEC_SEG, s1 = min(nseg, s0 + DEC_SEG);
     float s = 0.f;
-    for (int k = g; k < nblk; k += 16) s += part[((size_t)b * nblk + k) * DEC_NF + c];
+#pragma unroll 8
+    for (int k = s0 + q; k < s1; k += 4) s += src[(size_t)k * DEC_NF + c];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int st = 8; st >= 1; st >>= 1) {
-        if (g < st) red[threadIdx.x] += red[threadIdx.x + 64 * st];
-        __syncthreads();
-    }
-    if (g == 0) mean[c] = red[c] * inv_hw;
+    if (q == 0) part2[((size_t)b * ngrp + grp) * DEC_NF + c] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+    __threadfence();   // this workgroup's part2 row is visible device-wide before its arrival is
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(count + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(ngrp - 1)) return;
+    __threadfence();   // every other workgroup's row is visible here
+    const float* p2 = part2 + (size_t)b * ngrp * DEC_NF;
+    s = 0.f;
+#pragma unroll 4
+    for (int k = q; k < ngrp; k += 4) s += __builtin_nontemporal_load(p2 + (size_t)k * DEC_NF + c);
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0) mean[c] = ((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) * inv_hw;
     __syncthreads();
     if (threadIdx.x < DEC_SE_R) {
         float acc = 0.f;
@@ -723,33 +732,21 @@ __global__ void __launch_bounds__(1024) k_se_gate(const float* __restrict__ part
         hid[threadIdx.x] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    if (g == 0) {
+    if (q == 0) {
         float acc = 0.f;
         for (int r = 0; r < DEC_SE_R; ++r) acc += w2[c * DEC_SE_R + r] * hid[r];
         gate[(size_t)b * DEC_NF + c] = 1.f / (1.f + expf(-acc));
     }
-}
-// x <- x + x3 * gate  (decoder_rdn.py:40), and on the last block + shallow (the decoder's global residual, :78)
-__global__ void __launch_bounds__(256) k_se_apply(float* __restrict__ X, const float* __restrict__ T, const float* __restrict__ gate,
-                                                  const float* __restrict__ S, size_t n, int HW) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of 16 per pixel
-    if (i >= n * 16) return;
-    const size_t p = i >> 4; const int c = (int)(i & 15) * 4;
-    const int b = (int)(p / (size_t)HW);
-    const F4 t = *(const F4*)(T + p * DEC_NF + c), g = *(const F4*)(gate + (size_t)b * DEC_NF + c);
-    F4 x = *(const F4*)(X + p * DEC_CS + c);
-    x = x + t * g;
-    if (S) x = x + *(const F4*)(S + p * DEC_NF + c);
-    *(F4*)(X + p * DEC_CS + c) = x;
+    if (threadIdx.x == 0) count[b] = 0u;
 }
 
 // ---- entry ---------------------------------------------------------------------------------------------------------------
-template <int NT>
-static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = sizeof(float) * (size_t)(4 / NT + 2) * DEC_PX * DEC_CHS;
+static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {   // 64 output channels
+    const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
     const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY));
-    if (a.vec) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), lds, st, a);
+    if (a.se_part) hipLaunchKernelGGL((k_conv3x3<2, true, true>), grid, dim3(256), lds, st, a);
+    else if (a.vec) hipLaunchKernelGGL((k_conv3x3<2, true, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv3x3<2, false, false>), grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -757,26 +754,19 @@ template <int NR>
 static hipError_t launch_conv16(const ConvArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
     const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY));
-    if (a.vec) hipLaunchKernelGGL((k_conv16<NR, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_conv16<NR, false>), grid, dim3(256), lds, st, a);
+    if (a.fT) hipLaunchKernelGGL((k_conv16<NR, true, true>), grid, dim3(256), lds, st, a);
+    else if (a.vec) hipLaunchKernelGGL((k_conv16<NR, true, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv16<NR, false, false>), grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
 static hipError_t launch_convx(const ConvArgs& a, int nt, hipStream_t st) {
     const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 9 * 2 * 64 * 4);
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (lds > 64 * 1024 && !(done.load() >> dev & 1)) {   // per device, once: more than the default 64 KiB of dynamic LDS
-        e = hipFuncSetAttribute((const void*)k_conv3x3x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_conv3x3x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done.fetch_or(1ull << dev);
-    }
     const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY * nt));
-    if (a.vec) hipLaunchKernelGGL(k_conv3x3x<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(k_conv3x3x<false>, grid, dim3(256), lds, st, a);
+    if (a.fT) hipLaunchKernelGGL((k_conv3x3x<true, true, false>), grid, dim3(256), lds, st, a);
+    else if (a.se_part) hipLaunchKernelGGL((k_conv3x3x<true, false, true>), grid, dim3(256), lds, st, a);
+    else if (a.vec) hipLaunchKernelGGL((k_conv3x3x<true, false, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv3x3x<false, false, false>), grid, dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -790,59 +780,81 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     if (!shape || !d_bundle_feat || !d_packed || !d_ws || !d_rgb_c) return gdb_fail(GDB_E_BADARG, "NULL pointer");
     const int B = shape->B, H = shape->H, W = shape->W;
     if (B < 1 || H < 1 || W < 1) return gdb_fail(GDB_E_SHAPE, "non-positive bundle map");
+    if (B > 256) return gdb_fail(GDB_E_SHAPE, "decoder batch %d > 256", B);
     const int Q = 3 * cfg->bundle_size * cfg->bundle_size + GDB_CFR + GDB_CV, n_rgb = 3 * cfg->bundle_size * cfg->bundle_size;
     if (ld_bundle_feat < Q) return gdb_fail(GDB_E_SHAPE, "bundle_feat row stride %d < %d channels", ld_bundle_feat, Q);
     const DecWs ws = dec_ws(B, H, W);
     if (ws_bytes < ws.total) return gdb_fail(GDB_E_WORKSPACE, "decoder workspace %zu B < required %zu B", ws_bytes, ws.total);
-    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_CS ? ld_bundle_feat : DEC_CS) >= ((size_t)1 << 30))
+    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_NF ? ld_bundle_feat : DEC_NF) >= ((size_t)1 << 30))
         return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging byte offsets");
     const DecLayout L = dec_layout(num_layers);
     hipStream_t st = (hipStream_t)stream_;
-    float* X = (float*)((char*)d_ws + ws.X); float* S = (float*)((char*)d_ws + ws.S); float* T = (float*)((char*)d_ws + ws.T);
-    float* part = (float*)((char*)d_ws + ws.part); float* gate = (float*)((char*)d_ws + ws.gate);
+    float* P[3] = {(float*)((char*)d_ws + ws.P[0]), (float*)((char*)d_ws + ws.P[1]), (float*)((char*)d_ws + ws.P[2])};
+    float* Y = (float*)((char*)d_ws + ws.Y); float* T = (float*)((char*)d_ws + ws.T);
+    float* part = (float*)((char*)d_ws + ws.part); float* part2 = (float*)((char*)d_ws + ws.part2);
+    float* gate = (float*)((char*)d_ws + ws.gate); unsigned* count = (unsigned*)((char*)d_ws + ws.count);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (split) {   // per device, once: the split kernel's workgroup may take more than the default 64 KiB of dynamic LDS
+        const size_t lds = sizeof(unsigned) * ((size_t)(4 * DECX_ROWS + 2) * DEC_PX * DECX_PXD + 9 * 2 * 64 * 4);
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+        if (lds > 64 * 1024 && !(attr_done.load() >> dev & 1)) {
+            const void* fns[] = {(const void*)k_conv3x3x<true, true, false>, (const void*)k_conv3x3x<true, false, true>,
+                                 (const void*)k_conv3x3x<true, false, false>, (const void*)k_conv3x3x<false, false, false>};
+            for (const void* fn : fns) {
+                e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            attr_done.fetch_or(1ull << dev);
+        }
+    }
     auto conv = [&](ConvArgs a, int nt) -> hipError_t {
         a.B = B; a.H = H; a.W = W; a.tilesX = (W + 31) / 32;
         a.nchunk = (a.cin + 31) / 32;
+        if (!a.in2) a.split = a.nchunk;
         a.vec = (a.in_stride % 4 == 0) && (a.in_off % 4 == 0) && (a.cin % 4 == 0) && ((uintptr_t)a.in % 16 == 0);
         if (split) {
             a.tilesY = (H + 4 * DECX_ROWS - 1) / (4 * DECX_ROWS);
             return launch_convx(a, nt, st);
         }
-        if (nt == 2) { a.tilesY = (H + 1) / 2; return launch_conv<2>(a, st); }
-        a.tilesY = (H + 1) / 2;   // layers of <= 32 output channels: k_conv16, 2 rows x 2 pixel halves per workgroup
+        a.tilesY = (H + 1) / 2;   // every fp32 kernel: 2 rows x 32 pixels per workgroup
+        if (nt == 2) return launch_conv(a, st);
         return a.cout > 16 ? launch_conv16<2>(a, st) : launch_conv16<1>(a, st);
     };
     hipError_t e;
 #define CK(x) do { e = (x); if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "decoder launch: %s", hipGetErrorString(e)); } while (0)
-    {   // shallow = in_conv(bundle channels n_rgb..Q-1)   decoder_rdn.py:76; written as block 0's x and kept for the global residual
+    {   // shallow = in_conv(bundle channels n_rgb..Q-1)   decoder_rdn.py:76: block 0's x, and the global residual at the end
         ConvArgs a{};
         a.in = d_bundle_feat; a.in_stride = ld_bundle_feat; a.in_off = n_rgb; a.cin = Q - n_rgb;
         a.w = d_packed + (split ? L.in_wx : L.in_w); a.bias = d_packed + L.in_b;
-        a.out = X; a.out_stride = DEC_CS; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.out2 = S; a.out2_stride = DEC_NF;
+        a.out = P[0]; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.zero = count;
         CK(conv(a, 2));
     }
-    const size_t n = (size_t)B * H * W;
     for (int b = 0; b < num_layers; ++b) {   // ResidualDenseBlock.forward   decoder_rdn.py:35-41
         ConvArgs a{};
-        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.out = X; a.out_stride = DEC_CS; a.relu = 1;
-        a.cin = DEC_NF; a.w = d_packed + (split ? L.blkx[b][0] : L.blk[b][0]); a.out_off = DEC_NF; a.cout = DEC_G;
+        a.in_stride = DEC_NF; a.in_off = 0; a.out = Y; a.out_stride = DEC_NF; a.relu = 1;
+        // conv1; from the second block on it first forms its own input x_b = x_{b-1} + x3_{b-1} * gate_{b-1} (:40) and leaves it in P[b]
+        a.in = b ? P[b - 1] : P[0];
+        if (b) { a.fT = T; a.fgate = gate; a.fX = P[b]; }
+        a.cin = DEC_NF; a.w = d_packed + (split ? L.blkx[b][0] : L.blk[b][0]); a.out_off = 0; a.cout = DEC_G;
         CK(conv(a, 1));
-        a.cin = DEC_NF + DEC_G; a.w = d_packed + (split ? L.blkx[b][1] : L.blk[b][1]); a.out_off = DEC_NF + DEC_G;
+        a.fT = nullptr; a.fgate = nullptr; a.fX = nullptr;
+        a.in = P[b]; a.in2 = Y; a.split = 2;
+        a.cin = DEC_NF + DEC_G; a.w = d_packed + (split ? L.blkx[b][1] : L.blk[b][1]); a.out_off = DEC_G;
         CK(conv(a, 1));
-        a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + (split ? L.blkx[b][2] : L.blk[b][2]); a.out = T; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
+        a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + (split ? L.blkx[b][2] : L.blk[b][2]); a.out = T; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
+        a.se_part = part;
         CK(conv(a, 2));
-        hipLaunchKernelGGL(k_chan_partial, dim3((unsigned)(B * ws.nblk)), dim3(256), 0, st, T, H * W, ws.nblk, part);
-        CK(hipGetLastError());
-        hipLaunchKernelGGL(k_se_gate, dim3((unsigned)B), dim3(1024), 0, st, part, ws.nblk, 1.f / (float)((size_t)H * W), d_packed + L.blk[b][3],
-                           d_packed + L.blk[b][4], gate);
-        CK(hipGetLastError());
-        hipLaunchKernelGGL(k_se_apply, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st, X, T, gate,
-                           b == num_layers - 1 ? S : (const float*)nullptr, n, H * W);
+        hipLaunchKernelGGL(k_se_gate, dim3((unsigned)(B * ws.ngrp)), dim3(256), 0, st, part, ws.nseg, ws.ngrp, 1.f / (float)((size_t)H * W),
+                           d_packed + L.blk[b][3], d_packed + L.blk[b][4], part2, count, gate);
         CK(hipGetLastError());
     }
-    {   // out_conv(PixelShuffle(up(x))) as one folded 64 -> 12 convolution   decoder_rdn.py:79-80
+    {   // out_conv(PixelShuffle(up(x + shallow))) as one folded 64 -> 12 convolution on x = x_{L-1} + x3 * gate + shallow   :40,78-80
         ConvArgs a{};
-        a.in = X; a.in_stride = DEC_CS; a.in_off = 0; a.cin = DEC_NF; a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
+        a.in = P[num_layers - 1]; a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
+        a.fT = T; a.fgate = gate; a.fS = P[0];
+        a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
         a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
         CK(conv(a, 1));
     }
