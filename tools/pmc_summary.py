@@ -18,7 +18,7 @@ for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv")
     for (d, c), v in per.items():
         acc[names[d].split("(")[0]][c].append(v)
 for k in sorted(acc, key=lambda k: -sum(len(v) for v in acc[k].values())):
-    if not any(s in k for s in ("k_render", "k_pyr", "k_cam", "k_mlp", "k_encode", "k_prep")):
+    if not any(s in k for s in os.environ.get("PMC_KERNELS", "k_render k_pyr k_cam k_mlp k_encode k_prep k_flat").split()):
         continue
     print(f"== {k}")
     for c in sorted(acc[k]):
