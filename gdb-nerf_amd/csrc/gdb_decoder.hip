@@ -4,17 +4,16 @@
 // kernels for gfx950.
 //
 // * Layout: channel-last.  The fused hot path already writes bundle rows (N_b, Q) = (H, W, channels), so the decoder reads its
-//   27 input channels straight out of `bundle_feat` (no permute / slice copy), and the dense block's torch.cat([x, x1, x2]) is
-//   one (N_b, 128) buffer [x 64 | x1 32 | x2 32] whose later convolutions simply read more channels: no concatenation copies.
-// * 3x3 convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, the reference's precision):
-//   output channels on the MFMA rows (32 per tile), 32 consecutive pixels of an image row on the columns (= lanes), K = (tap,
-//   input channel).  The unit of work is ONE wave = one image-row segment of 32 pixels x one tile of 32 output channels (one
-//   accumulator): a workgroup's 4 waves are 4 rows (32-channel layers) or 2 rows x 2 output tiles (64-channel layers) of the
-//   same 32-pixel column, so that a 256x320 map gives 2560 / 5120 waves for the 1024 SIMDs (the first version's 8-row
-//   workgroups gave 320 workgroups for 256 CUs: a quarter of the CUs did double duty, 1.6 ms).  Per
-//   32-channel chunk of the input the workgroup stages its rows + halo in LDS (pixel stride 34 floats: the 8-byte B-operand
-//   reads of a wave are bank-conflict-free) and every wave runs 9 taps x 16 K-steps of MFMAs on it.  Weights are packed on the
-//   host in operand order (one float2 per lane per two K-steps, per output tile) and stream from L2.
+//   27 input channels straight out of `bundle_feat` (no permute / slice copy); activations are (N_b, 64) buffers and the dense
+//   block's torch.cat([x, x1, x2]) is "channels 0-63 from P[b], 64-127 from Y": no concatenation copies.
+// * 3x3 convolution = implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain, the reference's precision):
+//   16 output channels on the MFMA rows, 16 consecutive pixels of an image row on the columns, K = (tap, input channel).  A
+//   workgroup = 4 waves = 2 image rows x 32 pixels (1,280 workgroups on a 256x320 map = five per CU, all resident: five waves per
+//   SIMD by registers and LDS); a wave owns ONE 16-channel output tile and as many pixels as the layer allows - both rows (32-channel
+//   layers) or both rows and both 16-pixel halves (64-channel layers) - because every wave streams its tile's weights from L2 itself
+//   and the stream, not the matrix pipe, is what such a layer loses time to (k_conv16's comment has the measurements).  Per
+//   32-channel chunk of the input the workgroup stages its rows + halo in LDS (pixel stride 34 floats: the 4-byte B-operand reads of
+//   a wave are bank-conflict-free).  Weights are packed on the host in operand order as 16-byte packets (pack_conv16).
 // * The up stage is folded on the host: PixelShuffle is a permutation and there is no non-linearity between the 64 -> 256 up
 //   convolution and the 1x1 out_conv, so out_conv o PixelShuffle o up = ONE 3x3 convolution 64 -> 12 (4 sub-pixels x 3 colours;
 //   products summed in fp64, rounded once): 21x fewer flops for that stage, same function up to fp32 rounding.
@@ -22,8 +21,10 @@
 //   lo·hi + hi·lo + hi·hi on v_mfma_f32_32x32x16_f16 with fp32 accumulate — 3 x 32 cycles per 16 K instead of 8 x 64: the matrix
 //   time of a layer falls 5.3x and the kernel becomes a staging / weight-stream problem.  Activations are split when they are
 //   staged into LDS (hi and lo halves of a pixel's 32 channels side by side: the same 128 B as fp32), weights on the host.
-// * Squeeze-excitation: deterministic two-stage channel mean (per-block partial sums, reduced in a fixed order), the two tiny
-//   linears + sigmoid in one workgroup per batch item, and one element-wise pass x += x3 * gate (+ the global residual at the end).
+// * Squeeze-excitation has no pass of its own: conv3's epilogue leaves per-segment channel sums (a cross-lane tree on registers the
+//   wave holds anyway), ONE launch reduces them in a fixed order and runs the two tiny linears + sigmoid (k_se_gate, last-arriver
+//   pattern: deterministic), and x += x3 * gate (+ the global residual at the end) happens while the NEXT convolution stages its
+//   input (Stager<FUSE>).
 #include "gdb_internal.h"
 #include <atomic>
 #include <cstdlib>
@@ -39,7 +40,6 @@ typedef float F4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef unsigned U2 __attribute__((ext_vector_type(2)));
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 #define DEC_NF 64    // num_feats (network.py:51)
@@ -52,11 +52,7 @@ typedef unsigned U2 __attribute__((ext_vector_type(2)));
 #define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
 // ---- packed weights -------------------------------------------------------------------------------------------------
-// A convolution layer: [tile NT][chunk][tap 9][u2 4][lane 64][4] floats; element e of lane (i, h) = W[32 tile + i][32 chunk + 4 u +
-// 2 h + (e & 1)][tap] with u = 2 u2 + (e >> 1), zero beyond the layer's channels.  (K-step 2u + e' pairs the input channels 4u + e'
-// (half 0) and 4u + 2 + e' (half 1): a lane's two K-steps are two CONSECUTIVE channels, one 8-byte LDS read; one 16-byte packet =
-// four K-steps, so a tap is FOUR vector loads per wave - as 8-byte packets the weight stream alone kept the texture addresser busy
-// half of a 64-channel layer's matrix time and all of a 32-channel layer's: 16 cycles per wave load whatever its width.)
+// conv_floats(cin, nt): floats of a packed layer of 32 nt output channels (fp32 form pack_conv16 and split-f16 form pack_conv_x alike).
 static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 9 * 8 * 64 * 2 * nt; }
 struct DecLayout {
     size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
@@ -88,26 +84,11 @@ static DecLayout dec_layout(int nlayers) {
     return L;
 }
 // w: (cout, cin, 3, 3) row-major as torch stores it
-static void pack_conv(const float* w, int cout, int cin, int nt, float* out) {
-    const int nchunk = (cin + 31) / 32;
-    for (int t = 0; t < nt; ++t)
-        for (int ch = 0; ch < nchunk; ++ch)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int u2 = 0; u2 < 4; ++u2)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 4; ++e) {
-                            const int u = 2 * u2 + (e >> 1);
-                            int i = l & 31, h = l >> 5, co = 32 * t + i, ci = 32 * ch + 4 * u + 2 * h + (e & 1);
-                            float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
-                            out[(((((size_t)t * nchunk + ch) * 9 + tap) * 4 + u2) * 64 + l) * 4 + e] = v;
-                        }
-}
-
-// A layer of at most 32 output channels for k_conv16 (v_mfma_f32_16x16x4_f32: 16 output rows x 16 pixels x 4 input channels per
-// instruction, the same FLOP rate as the 32x32x2 form): [tile mt][chunk][tap 9][g4 2][lane 64][4] floats; element e of lane l =
+// A layer for k_conv16 (v_mfma_f32_16x16x4_f32: 16 output rows x 16 pixels x 4 input channels per instruction, the same FLOP rate
+// as the 32x32x2 form): [tile mt][32-channel chunk][tap 9][g4 2][lane 64][4] floats; element e of lane l =
 // W[16 mt + (l & 15)][32 chunk + 4 (4 g4 + e) + (l >> 4)][tap] - the lane supplies A[row l & 15][k = l >> 4] of output tile mt for
 // four consecutive k-groups: a tap of one tile is TWO 16-byte vector loads per wave.  A layer of <= 16 channels packs tile 0 only.
-// Never larger than pack_conv's one-tile form.
+// Four tiles = conv_floats(cin, 2).
 static void pack_conv16(const float* w, int cout, int cin, float* out) {
     const int nchunk = (cin + 31) / 32, nmt = (cout + 15) / 16;
     for (int mt = 0; mt < nmt; ++mt)
@@ -168,14 +149,14 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
     const DecLayout L = dec_layout(num_layers);
     memset(out, 0, sizeof(float) * L.total);
     const int cin0 = GDB_CFR + GDB_CV;  // 27
-    pack_conv(t[0], DEC_NF, cin0, 2, out + L.in_w);
+    pack_conv16(t[0], DEC_NF, cin0, out + L.in_w);
     pack_conv_x(t[0], DEC_NF, cin0, 2, out + L.in_wx);
     memcpy(out + L.in_b, t[1], sizeof(float) * DEC_NF);
     for (int b = 0; b < num_layers; ++b) {
         const float* const* q = t + 2 + 5 * b;
         pack_conv16(q[0], DEC_G, DEC_NF, out + L.blk[b][0]);
         pack_conv16(q[1], DEC_G, DEC_NF + DEC_G, out + L.blk[b][1]);
-        pack_conv(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blk[b][2]);
+        pack_conv16(q[2], DEC_NF, DEC_NF + 2 * DEC_G, out + L.blk[b][2]);
         pack_conv_x(q[0], DEC_G, DEC_NF, 1, out + L.blkx[b][0]);
         pack_conv_x(q[1], DEC_G, DEC_NF + DEC_G, 1, out + L.blkx[b][1]);
         pack_conv_x(q[2], DEC_NF, DEC_NF + 2 * DEC_G, 2, out + L.blkx[b][2]);
@@ -351,128 +332,56 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
-// NT = output tiles of the layer (2: 64 channels, 2 rows x 2 tiles per workgroup).  One wave = one image-row segment of 32 pixels x one
-// tile of 32 output channels (one accumulator).  SEP: the epilogue also leaves the segment's per-channel sums of the output for the
-// squeeze-excitation mean (decoder_rdn.py:17-21) - a cross-lane tree on registers the wave holds anyway, instead of a pass over T.
-template <int NT, bool VEC, bool SEP>
-__global__ void __launch_bounds__(256, 5) k_conv3x3(ConvArgs a) {
-    constexpr int TR = 4 / NT;   // rows per workgroup
-    float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int t = wid % NT, wrow = wid / NT;   // this wave's output tile and row of the workgroup
-    const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
-    const int x0 = bx * 32, y0 = by * TR;
-    if (a.zero && blockIdx.x == 0 && tid < a.B) a.zero[tid] = 0u;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-        acc[r] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
-    }
-    Stager<TR, 8, VEC, false> st;
-    st.init(a, tid, b, x0, y0);
-    const int loff0 = (tid >> 3) * DEC_CHS + st.g4;   // float offset of slot 0 in LDS; slot s lies 32 pixels further
-    const float* wbase = a.w + (size_t)t * a.nchunk * 9 * 8 * 64 * 2;   // wave-uniform
-    const unsigned wlane = 16u * (unsigned)lane;
-    const float* brow = lds + (size_t)(wrow * DEC_PX + j) * DEC_CHS + 2 * h;
-    // (Measured for the 64-channel layers too, although the chunk in flight costs registers: decoder 0.804 -> 0.771 ms with the loads
-    // ahead in both, 0.780 in the 32-channel layers only.)
-    st.fetch(a, b, 0);
-    // weights: a tap = 4 packets = two halves of 8 MFMAs; the next half's 2 packets are loaded while the current half's MFMAs run (L2
-    // latency under the matrix pipe: 512 matrix cycles of this wave, five times that with its SIMD-mates).  A whole tap ahead costs 16
-    // more registers, which at five waves per SIMD (96) is a spill.
-    F4 wn[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) wn[u] = ldu<F4>(wbase, wlane + 1024u * u);
-    for (int ch = 0; ch < a.nchunk; ++ch) {
-        __syncthreads();  // the previous chunk's reads are done
-#pragma unroll
-        for (int s = 0; s < st.NSLOT; ++s) {
-            if (!st.has(s, tid)) continue;
-            const F4 v = st.value(a, s, ch);
-            F2* dst = (F2*)(lds + loff0 + s * 32 * DEC_CHS);  // 8-byte aligned (DEC_CHS is even)
-            dst[0] = F2{v[0], v[1]}; dst[1] = F2{v[2], v[3]};
-        }
-        __syncthreads();
-        if (ch + 1 < a.nchunk) st.fetch(a, b, ch + 1);   // flies under this chunk's MFMAs
-#pragma unroll
-        for (int hp = 0; hp < 18; ++hp) {   // (tap, half)
-            const int tap = hp >> 1, dy = tap / 3, dx = tap % 3, u0 = 4 * (hp & 1);
-            F4 w[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) w[u] = wn[u];
-            {   // prefetch: the next half of this chunk, or the first of the next chunk (the last prefetch of the layer reads the
-                // packed buffer's next layer / tail padding: in bounds by construction of dec_layout, never used)
-                const float* wnext = wbase + ((size_t)ch * 18 + hp + 1) * 4 * 128;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) wn[u] = ldu<F4>(wnext, wlane + 1024u * u);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // the loads stay ahead of these MFMAs (left alone the scheduler sank each next to its use)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const F2 bv = *(const F2*)(brow + (size_t)(dy * DEC_PX + dx) * DEC_CHS + 4 * (u0 + u));
-                acc = MFMA32(w[u >> 1][2 * (u & 1)], bv[0], acc);
-                acc = MFMA32(w[u >> 1][2 * (u & 1) + 1], bv[1], acc);
-            }
-        }
-    }
-    // epilogue: lane (j, h) holds output channels 32 t + 8 g + 4 h + (0..3) of pixel (y, x0 + j)
-    const int x = x0 + j, y = y0 + wrow;
-    const bool valid = x < a.W && y < a.H;
-    if (SEP && y < a.H) {   // (wave-uniform) the segment's channel sums: part[b][y * tilesX + bx][64]
-        float* dst = a.se_part + (((size_t)b * a.H + y) * a.tilesX + bx) * DEC_NF + 32 * t + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            F4 sum;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sum[k] = half_wave_sum(valid ? acc[4 * g + k] : 0.f);
-            if (j == 0) *(F4*)(dst + 8 * g) = sum;
-        }
-    }
-    if (!valid) return;
-    const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co = 32 * t + 8 * g + 4 * h;
-        if (co >= a.cout) continue;
-        F4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;   // all buffers: strides and offsets multiples of 4
-    }
+// Sum of v over the 16 lanes of the caller's row group (fixed tree), valid in every lane.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
 }
 
-
-// Layers of at most 32 output channels (conv1, conv2 of a dense block; the folded up stage with its 12) on v_mfma_f32_16x16x4_f32.
-// The 32x32x2 kernel above gives such a layer 2,560 equal waves for 1,024 SIMDs on a 256x320 map - half the SIMDs run three of them,
-// half two, and the layer takes three units of time for 2.5 units of work - and the 12-channel up stage wastes 20 of its 32 MFMA rows.
-// Here a workgroup is 2 image rows x 32 pixels and a wave 16 pixels of it:
-//   NR = 2 (17..32 output channels): wave (pixel half, tile mt) renders BOTH rows of ONE 16-channel tile - the two rows share every
-//          weight packet, so the wave streams 18 KiB of weights per 32-channel chunk instead of the 36 KiB a (row, half) wave with both
-//          tiles needs (round 3's form: its weight loads alone, 72 per chunk and wave at 16 addresser cycles each, equalled the
-//          layer's matrix time);
-//   NR = 1 (<= 16 output channels):  wave (pixel half, row), tile 0.
-// Either way 5,120 equal waves on a 256x320 map = five per SIMD.  Staging is the 32x32x2 kernel's (rows + halo of a 32-channel chunk
-// in LDS, pixel stride 34 floats: lane l reads channel 4 g + (l >> 4) of pixel l & 15, 64 distinct banks); a B operand is one
-// ds_read_b32; weights stream from L2 as 16-byte packets = four k-groups (pack_conv16), the next tap's under the current tap's MFMAs.
-template <int NR, bool VEC, bool FUSE>
+// Every fp32 convolution of the decoder, on v_mfma_f32_16x16x4_f32.  A workgroup is 2 image rows x 32 pixels = 4 waves; a wave owns
+// ONE 16-channel output tile mt and as many of the workgroup's pixels as the layer's tile count leaves it:
+//   NPH = 2, NR = 2 (64 output channels: in_conv, conv3): wave = tile mt of four; both rows, both 16-pixel halves = 64 pixels, four
+//          accumulators;
+//   NPH = 1, NR = 2 (17..32 channels: conv1, conv2):      wave = (pixel half, tile mt of two); both rows = 32 pixels;
+//   NPH = 1, NR = 1 (<= 16 channels: the folded up stage): wave = (pixel half, row), tile 0 = 16 pixels.
+// Either way 5,120 equal waves on a 256x320 map = five per SIMD, all resident (<= 96 registers, 18.5 KB of LDS per workgroup).
+// Why pixels per wave matter: each wave streams its tile's weights from L2 itself (16-byte packets = four k-groups, the next tap's
+// requested under the current tap's MFMAs), a packet feeds NPH x NR MFMAs, and that stream - not the matrix pipe, not the staging -
+// is what a layer loses time to.  Measured on one box (profiles/r04/decoder_experiments.txt): the 128 -> 64 layer as 32 pixels x 32
+// channels per wave on v_mfma_f32_32x32x2_f32 (147 KB of weights per wave) 108.7 us, as 64 pixels x 16 channels (74 KB) 95.7 us, its
+// bare MFMA loop ~87; round 3's 8-byte packets with a (row, half) wave on both tiles of a 32-channel layer: the weight loads alone,
+// 72 per chunk and wave at 16 addresser cycles each, equalled the layer's matrix time.  The pixels come from LDS, which has the
+// bandwidth: rows + halo of a 32-channel chunk, pixel stride 34 floats (lane l reads channel 4 g + (l >> 4) of pixel l & 15: 64
+// distinct banks), one ds_read_b32 per MFMA.
+// SEP: the epilogue also leaves the segment's per-channel sums of the output for the squeeze-excitation mean (decoder_rdn.py:17-21) -
+// a cross-lane tree on registers the wave holds anyway, instead of a pass over T.
+template <int NR, bool VEC, bool FUSE, int NPH = 1, bool SEP = false>
 __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
     constexpr int TR = 2;        // rows per workgroup
     float* lds = dsmem;          // [(TR + 2)][DEC_PX][DEC_CHS]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, kq = lane >> 4;
-    const int ph = wid & 1;                       // this wave's 16-pixel half of the column
-    const int mt = NR == 2 ? wid >> 1 : 0;        // its 16-channel output tile
-    const int wrow = NR == 2 ? 0 : wid >> 1;      // its first row of the workgroup
+    const int ph = NPH == 2 ? 0 : wid & 1;                        // this wave's (first) 16-pixel half of the column
+    const int mt = NPH == 2 ? wid : (NR == 2 ? wid >> 1 : 0);     // its 16-channel output tile
+    const int wrow = NR == 2 ? 0 : wid >> 1;                      // its first row of the workgroup
     const int bx = blockIdx.x % a.tilesX, by = (blockIdx.x / a.tilesX) % a.tilesY, b = blockIdx.x / (a.tilesX * a.tilesY);
     const int x0 = bx * 32, y0 = by * TR;
-    F4 acc[NR];   // D layout: register r of lane l = output row 4 (l >> 4) + r of pixel l & 15
+    if (a.zero && blockIdx.x == 0 && tid < a.B) a.zero[tid] = 0u;
+    F4 acc[NPH][NR];   // D layout: register r of lane l = output row 4 (l >> 4) + r of pixel l & 15
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = 16 * mt + 4 * kq + r;
         const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NR; ++q) acc[q][r] = bv;
+        for (int p = 0; p < NPH; ++p)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[p][q][r] = bv;
     }
     Stager<TR, 8, VEC, FUSE> st;
     st.init(a, tid, b, x0, y0);
@@ -510,36 +419,58 @@ __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    const float bv = brow[(size_t)((dy + q) * DEC_PX + dx) * DEC_CHS + 4 * g];
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g >> 2][g & 3], bv, acc[q], 0, 0, 0);
-                }
+                for (int p = 0; p < NPH; ++p)
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        const float bv = brow[(size_t)((dy + q) * DEC_PX + dx + 16 * p) * DEC_CHS + 4 * g];
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g >> 2][g & 3], bv, acc[p][q], 0, 0, 0);
+                    }
             }
         }
     }
-    // epilogue: lane (pl, kq) holds output channels 16 mt + 4 kq + (0..3) of pixels (y0 + wrow + q, x0 + 16 ph + pl)
-    const int x = x0 + 16 * ph + pl;
+    // epilogue: lane (pl, kq) holds output channels 16 mt + 4 kq + (0..3) of pixels (y0 + wrow + q, x0 + 16 (ph + p) + pl)
     const int co = 16 * mt + 4 * kq;
-    if (x >= a.W || co >= a.cout) return;
+    if (SEP) {   // the segment's channel sums: part[b][y * tilesX + bx][64]; a sum over the 16 lanes of a row group, both pixel halves
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        const int y = y0 + wrow + q;
-        if (y >= a.H) continue;
-        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-        F4 v = acc[q];
-        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
-            const int Ho = 2 * a.H, Wo = 2 * a.W;
+        for (int q = 0; q < NR; ++q) {
+            const int y = y0 + wrow + q;
+            if (y >= a.H) continue;   // (wave-uniform)
+            F4 sum;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c = co + k;
-                if (c < 12) {
-                    const int sp = c / 3, o = c - 3 * sp;
-                    a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (sp >> 1)) * Wo + 2 * x + (sp & 1)] = v[k];
-                }
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < NPH; ++p) v += (x0 + 16 * (ph + p) + pl < a.W) ? acc[p][q][k] : 0.f;
+                sum[k] = row16_sum(v);
             }
-        } else {
-            *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
+            if (pl == 0) *(F4*)(a.se_part + (((size_t)b * a.H + y) * a.tilesX + bx) * DEC_NF + co) = sum;
+        }
+    }
+    if (co >= a.cout) return;
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+        const int x = x0 + 16 * (ph + p) + pl;
+        if (x >= a.W) continue;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int y = y0 + wrow + q;
+            if (y >= a.H) continue;
+            const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+            F4 v = acc[p][q];
+            if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
+                const int Ho = 2 * a.H, Wo = 2 * a.W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = co + k;
+                    if (c < 12) {
+                        const int sp = c / 3, o = c - 3 * sp;
+                        a.rgb[(((size_t)b * 3 + o) * Ho + 2 * y + (sp >> 1)) * Wo + 2 * x + (sp & 1)] = v[k];
+                    }
+                }
+            } else {
+                *(F4*)(a.out + pix * a.out_stride + a.out_off + co) = v;
+            }
         }
     }
 }
@@ -744,9 +675,9 @@ __global__ void __launch_bounds__(256) k_se_gate(const float* __restrict__ part,
 static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {   // 64 output channels
     const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
     const dim3 grid((unsigned)(a.B * a.tilesX * a.tilesY));
-    if (a.se_part) hipLaunchKernelGGL((k_conv3x3<2, true, true>), grid, dim3(256), lds, st, a);
-    else if (a.vec) hipLaunchKernelGGL((k_conv3x3<2, true, false>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_conv3x3<2, false, false>), grid, dim3(256), lds, st, a);
+    if (a.se_part) hipLaunchKernelGGL((k_conv16<2, true, false, 2, true>), grid, dim3(256), lds, st, a);     // conv3
+    else if (a.vec) hipLaunchKernelGGL((k_conv16<2, true, false, 2, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv16<2, false, false, 2, false>), grid, dim3(256), lds, st, a);             // in_conv
     return hipGetLastError();
 }
 

@@ -20,26 +20,6 @@ def _dec_state(f7):
     return {k[len("sd.upsampler."):]: np.asarray(v, dtype=np.float32) for k, v in f7.items() if k.startswith("sd.upsampler.")}  # (the fixture stores exactly-representable tensors as float16)
 
 
-def _unpack_conv(packed, cout, cin, nt):
-    """Inverse of pack_conv (gdb_decoder.hip): [tile][chunk][tap][u2 4][lane][e 4] -> (cout, cin, 3, 3); element e of lane (i, h) is
-    input channel 32 chunk + 4 u + 2 h + (e & 1) with u = 2 u2 + (e >> 1)."""
-    nchunk = (cin + 31) // 32
-    a = packed[:nt * nchunk * 9 * 4 * 64 * 4].reshape(nt, nchunk, 9, 4, 64, 4)
-    w = np.zeros((cout, cin, 9), np.float32)
-    for t in range(nt):
-        for ch in range(nchunk):
-            for u2 in range(4):
-                for l in range(64):
-                    i, h = l & 31, l >> 5
-                    for e in range(4):
-                        co, ci = 32 * t + i, 32 * ch + 4 * (2 * u2 + (e >> 1)) + 2 * h + (e & 1)
-                        if co < cout and ci < cin:
-                            w[co, ci, :] = a[t, ch, :, u2, l, e]
-                        else:
-                            assert np.all(a[t, ch, :, u2, l, e] == 0)
-    return w.reshape(cout, cin, 3, 3)
-
-
 def _unpack_conv16(packed, cout, cin):
     """Inverse of pack_conv16 (layers of <= 32 output channels, v_mfma_f32_16x16x4_f32 operand order): [tile mt][chunk][tap][g4 2]
     [lane][e 4] -> (cout, cin, 3, 3); element e of lane l = W[16 mt + (l & 15)][32 chunk + 4 (4 g4 + e) + (l >> 4)][tap]; a layer of
@@ -94,12 +74,12 @@ def test_packed_decoder_weights_and_the_folded_up_stage():
     assert np.isfinite(host).all()
     conv_floats = lambda cin, nt: ((cin + 31) // 32) * 9 * 8 * 64 * 2 * nt
     o = 0
-    assert np.array_equal(_unpack_conv(host[o:], 64, 27, 2), sd["in_conv.weight"]); o += conv_floats(27, 2)
+    assert np.array_equal(_unpack_conv16(host[o:], 64, 27), sd["in_conv.weight"]); o += conv_floats(27, 2)
     assert np.array_equal(host[o:o + 64], sd["in_conv.bias"]); o += 64
     for i in range(3):
         assert np.array_equal(_unpack_conv16(host[o:], 32, 64), sd[f"blocks.{i}.conv1.weight"]); o += conv_floats(64, 1)
         assert np.array_equal(_unpack_conv16(host[o:], 32, 96), sd[f"blocks.{i}.conv2.weight"]); o += conv_floats(96, 1)
-        assert np.array_equal(_unpack_conv(host[o:], 64, 128, 2), sd[f"blocks.{i}.conv3.weight"]); o += conv_floats(128, 2)
+        assert np.array_equal(_unpack_conv16(host[o:], 64, 128), sd[f"blocks.{i}.conv3.weight"]); o += conv_floats(128, 2)
         assert np.array_equal(host[o:o + 256].reshape(4, 64), sd[f"blocks.{i}.se.fc.0.weight"]); o += 256
         assert np.array_equal(host[o:o + 256].reshape(64, 4), sd[f"blocks.{i}.se.fc.2.weight"]); o += 256
     wf = torch.from_numpy(_unpack_conv16(host[o:], 12, 64)); o += conv_floats(64, 1)
@@ -121,7 +101,7 @@ def test_packed_decoder_weights_and_the_folded_up_stage():
     fp32["up"] = (q, 12, 64, 1)
     for key in ["in"] + [f"{i}{c}" for i in range(3) for c in ("c1", "c2", "c3")] + ["up"]:
         off, cout, cin, nt = fp32[key]
-        w = _unpack_conv(host[off:], cout, cin, nt) if nt == 2 else _unpack_conv16(host[off:], cout, cin)
+        w = _unpack_conv16(host[off:], cout, cin)
         hi, lo = _unpack_conv_x(host[o:], cout, cin, nt)
         assert np.array_equal(hi, w.astype(np.float16).astype(np.float32)), key
         assert np.all(np.abs(hi.astype(np.float64) + lo - w) <= np.abs(w) * 2.0 ** -21 + 2.0 ** -25), key
