@@ -1195,7 +1195,13 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
 // section layout above) — no conversion, no LDS, no lane movement; ReLU is one integer max per register.
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ f32x4 load_quad(const float* __restrict__ m32, int q, int lane) {
+#if defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // timing experiment (wrong results): no weight loads at all
+    f32x4 r; asm volatile("" : "=v"(r)); return r;
+#elif defined(GDB_XP_NOW) && GDB_XP_NOW == 2  // timing experiment (wrong results): every weight load hits the same 1 KiB (L1-resident)
+    return ldu_pin<f32x4>(m32 + (size_t)(q & 1) * 256, (unsigned)lane * 16u);
+#else
     return ldu_pin<f32x4>(m32 + (size_t)q * 256, (unsigned)lane * 16u);
+#endif
 }
 // acc += W[:, steps] · b over NS steps whose weight quads are already in registers
 template <int NS>
