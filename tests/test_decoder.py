@@ -167,3 +167,28 @@ def test_hip_decoder_matches_torch_module(B, H, W, layers, prec):
         eng.decode(bf[:-1])
     with pytest.raises(ValueError, match="precision"):
         eng.decode(bf, precision=0)
+
+
+@pytest.mark.gpu
+@PRECS
+def test_hip_decoder_does_not_depend_on_the_workspace_contents(prec):
+    """The workspace is the caller's scratch and arrives uninitialised: the squeeze-excitation's arrival counters are cleared by the
+    decode call itself (in_conv's launch), the channel sums and gates are written before they are read.  Garbage (all ones bits,
+    then random bytes) in the workspace before the call must leave the result bit-identical, batch 2, ragged map, every block."""
+    torch.manual_seed(5)
+    dec = Decoder(27, 3, num_feats=64, num_layers=3, upscale_factor=2).cuda().eval()
+    B, H, W = 2, 37, 70
+    eng = _engine(B, H, W, {k: v.detach() for k, v in dec.state_dict().items()}, 3)
+    bf = torch.zeros((B * H * W, 41), device="cuda")
+    bf[:, 12:39] = torch.randn(B * H * W, 27, device="cuda")
+    want = eng.decode(bf, precision=prec).clone()
+    for fill in ("ones", "random"):
+        if fill == "ones":
+            eng._dec_ws.fill_(0xFF)
+        else:
+            eng._dec_ws.copy_(torch.randint(0, 256, (eng._dec_ws.numel(),), dtype=torch.uint8, device="cuda"))
+        got = eng.decode(bf, precision=prec)
+        assert torch.equal(got, want), fill
+    with torch.no_grad():
+        ref = dec(bf[:, 12:39].view(B, H, W, 27).permute(0, 3, 1, 2).contiguous())
+    assert max_abs(want.cpu().numpy(), ref.cpu().numpy()) <= 3e-5 * max(1.0, float(ref.abs().max()))
