@@ -699,6 +699,22 @@ __device__ __forceinline__ void rgb_combine(const RgbTaps& t, const RgbData& d, 
 }
 
 extern __shared__ float4 smem4[];
+// Wave priority by progress (s_setprio; the SIMD's arbiter otherwise favours the oldest wave, which then finishes first and leaves
+// its mates to end the launch alone): a wave with tiles (slots) still to come outranks a wave on its last one, and within a tile the
+// gather phase - address arithmetic and load issue, whose latency everything else waits for - outranks the MLP / composite phases.
+// Measured (profiles/r04/ab_wave_priority.txt, same box): k_render_dense c2 f32 -0.8 %, c2 f16 -3.0 %, c4 f32 -2.3 %, c4 f16 -4.1 %;
+// k_render_flat +1.9 % (two equal tiles per wave: left alone); the inverse senses lose everywhere.
+template <bool ON>
+__device__ __forceinline__ void wave_prio(bool last_tile, bool gather) {
+    if constexpr (ON) {
+        if (!last_tile) { if (gather) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+        else            { if (gather) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    }
+}
+#ifndef GDB_XP_PRIO_SOLO
+#define GDB_XP_PRIO_SOLO 0
+#endif
+
 
 // This lane's 12 staged feature values (channels 8s+4h+e, the accumulator rows it owns) and, for half
 // 0, the 4 direction values; from them the two f16 operand fragments of the per-view tail vector
@@ -1693,6 +1709,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
     for (int i = 0; i < 4; ++i) of[i] = 0.f;
     const int S = ap->f.S_max;
     for (int k = 0; k < S; ++k) {
+        wave_prio<GDB_XP_PRIO_SOLO != 0>(k + 1 >= S, true);
         KArgs* apk = ap;
         asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
         // (a by-value copy per slot, as k_render_dense makes per tile, LOSES here: c5 f16 926 -> 970 us - this kernel has no register to spare)
@@ -1716,6 +1733,7 @@ __global__ void __launch_bounds__(64, WPS) k_render_solo(FusedArgs a_) {
         const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
         float z; float vox[4];
         slot_gather_q<PREC>(f, stage, tc, q, k, bi, j, h, a.skip, act, z, vox);
+        wave_prio<GDB_XP_PRIO_SOLO != 0>(k + 1 >= S, false);
         __builtin_amdgcn_wave_barrier();
         PHASE_FENCE();
         float bacc[16], fhv[4], sig;
@@ -1883,6 +1901,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
     if (ntile <= 0) return;
     int it = 0;
     do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
+    wave_prio<PERSIST>(it + 1 >= ntile, true);   // (the one-tile form measured 1 % slower with it: c3)
     KArgs* apk = ap;
     if constexpr (PERSIST) asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
     // The arguments as VALUES: the by-value kernel parameter when the wave renders one tile (the compiler fetches it in a few wide
@@ -1945,6 +1964,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
     STAMP(2);
+    wave_prio<PERSIST>(it + 1 >= ntile, false);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
@@ -2151,6 +2171,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
     if (ntile <= 0) return;
     int it = 0;
     do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
+    wave_prio<false>(!PERSIST || it + 1 >= ntile, true);
     KArgs* apk = ap;
     if constexpr (PERSIST) asm volatile("" : "+s"(apk));
     const FusedArgs a_copy = *(const FusedArgs*)apk;   // the arguments as values (see k_render_dense)
@@ -2222,6 +2243,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
     STAMP(2);
+    wave_prio<false>(!PERSIST || it + 1 >= ntile, false);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
