@@ -316,7 +316,7 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
 constexpr int NBLEND = 3 * 4 + GDB_CFR;      // 31 blended channels per view: 12 rgbs + 19 feat ⊕ rgb
 constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // Per (wave, view) staging in LDS: rows of 32 bundles holding the reference's per-view vector [rgbs 12 | feat ⊕ rgb 19 | dir 4]
-// (bundle_sampler.py:369) - 35 fp32 rows, one per channel, at GDB_PREC_F32 / F32X; 27 rows at GDB_PREC_F16 (see row_feat<> below).
+// (bundle_sampler.py:369) - 35 fp32 rows, one per channel, at GDB_PREC_F32 / F32X; 18 rows of packed halves at GDB_PREC_F16 (see row_feat<> below).
 // Timing-only ablation bits (GDB_FUSED_SKIP; 1 colours, 2 features, 4 volume, 8 MLP) exist only in the diagnostic build
 // -DGDB_DEBUG_SKIP: as runtime branches they split the gather into basic blocks and defeat its load scheduling.
 #ifdef GDB_DEBUG_SKIP
@@ -327,13 +327,19 @@ constexpr int NOUT = NBLEND + GDB_CV;        // 39
 // At GDB_PREC_F16 the 4 direction values are only ever an f16 MFMA operand: they are staged as two rows of packed halves
 // (dir0|dir1, dir2|dir3) - the same rounding, just earlier.  (The LDS allocation granule is 1280 B: tools/ubench/simd_map.hip.)
 constexpr int COMP_LD = 33;                  // padded bundle stride of the composite record
-// GDB_PREC_F16 goes one step further: the 12 sub-ray colours (values in [0, 1]) are staged as 6 rows of packed halves too (round
-// to nearest: 2.4e-4 at most, inside that path's 2e-3 bound), 27 rows = 3,456 B per view, so that five views (c5) are 17,280 B per
-// wave and a CU holds 9 waves instead of 7.
-// Rows of a staged view: [colours | feat (+) rgb 19 | dir]
+// GDB_PREC_F16 goes further: the 12 sub-ray colours (values in [0, 1]) are staged as 6 rows of packed halves (round to nearest:
+// 2.4e-4 at most, inside that path's 2e-3 bound), and so are the 19 channels of feat (+) rgb - sums of taps of the HALF-precision
+// pyramid that are about to become f16 MFMA operands anyway - as 10 rows of channel pairs (2c, 2c + 1), channel 19 = 0:
+// 18 rows = 2,304 B per view.  Five views (c5) are 11,520 B per wave: LDS would hold 14 waves on a CU, so the segment-wave kernel
+// runs the 12 its registers allow (27 rows with fp32 features: 9 waves; 35 fp32 rows: 7).
+// Rows of a staged view: [colours | feat (+) rgb | dir]
 template <int PREC> constexpr int row_feat() { return PREC == GDB_PREC_F16 ? 6 : 12; }
-template <int PREC> constexpr int row_dir() { return row_feat<PREC>() + GDB_CFR; }
-template <int PREC> constexpr int stage_v() { return (row_dir<PREC>() + (PREC != GDB_PREC_F16 ? 4 : 2)) * 32; }  // floats per (wave, view): 3456 / 4480 B
+template <int PREC> constexpr int feat_rows() { return PREC == GDB_PREC_F16 ? 10 : GDB_CFR; }
+template <int PREC> constexpr int row_dir() { return row_feat<PREC>() + feat_rows<PREC>(); }
+template <int PREC> constexpr int stage_v() { return (row_dir<PREC>() + (PREC != GDB_PREC_F16 ? 4 : 2)) * 32; }  // floats per (wave, view): 2304 / 4480 B
+typedef _Float16 hpair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_h2(float a, float b) { const hpair p = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, p); }
+__device__ __forceinline__ hpair unpack_h2(unsigned u) { return __builtin_bit_cast(hpair, u); }
 // Blended output channels of lane (j, h), register i of 16: the 6 colours of ITS OWN two sub-rays (channel c b^2 + 2h + e, the
 // ones its half gathered), then 10 (half 0) / 9 (half 1) channels of feat (+) rgb.  -1: no channel (half 1's last register).
 __device__ __forceinline__ constexpr int own_chan(int h, int i) {
@@ -385,6 +391,16 @@ __device__ __forceinline__ void load_blend16(const float* __restrict__ st, int j
         const float* sa = st + h * (2 * 32);
 #pragma unroll
         for (int i = 0; i < 6; ++i) val[i] = sa[((i >> 1) * 4 + (i & 1)) * 32 + j];
+    }
+    if constexpr (PREC == GDB_PREC_F16) {   // channels 10h .. 10h + 9 = packed rows 5h .. 5h + 4 (channel 19 is stored as 0)
+        const unsigned* sp = (const unsigned*)st + (row_feat<PREC>() + 5 * h) * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const hpair p = unpack_h2(sp[r * 32]);
+            val[6 + 2 * r] = (float)p.x; val[7 + 2 * r] = (float)p.y;
+        }
+        if (h) val[15] = 0.f;
+        return;
     }
     const float* sb = st + h * (10 * 32);
 #pragma unroll
@@ -724,6 +740,32 @@ template <bool X>
 __device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j, int h) {
     constexpr int RF = row_feat<X ? GDB_PREC_F32X : GDB_PREC_F16>(), RD = row_dir<X ? GDB_PREC_F32X : GDB_PREC_F16>();
     Tail<X> t;
+    if constexpr (!X) {   // GDB_PREC_F16: packed channel pairs - the staged halves ARE the operand elements
+        const unsigned* su = (const unsigned*)st + j;
+        _Float16 hv[12];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {   // channels 8s + 4h + 2r, + 1 = packed row 4s + 2h + r
+                const hpair p = unpack_h2(su[(RF + 4 * s + 2 * h + r) * 32]);
+                hv[4 * s + 2 * r] = p.x; hv[4 * s + 2 * r + 1] = p.y;
+            }
+        {   // channels 16 .. 19 (half 0; 19 is stored as 0) / none (half 1)
+            const hpair p = unpack_h2(h == 0 ? su[(RF + 8) * 32] : 0u), q = unpack_h2(h == 0 ? su[(RF + 9) * 32] : 0u);
+            hv[8] = p.x; hv[9] = p.y; hv[10] = q.x; hv[11] = q.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t.fv[i] = (float)hv[i];
+        const unsigned d01 = h == 0 ? su[(RD + 0) * 32] : 0u, d23 = h == 0 ? su[(RD + 1) * 32] : 0u;
+        const hpair p01 = unpack_h2(d01), p23 = unpack_h2(d23);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t.T0.hi[i] = hv[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t.T1.hi[i] = hv[8 + i];  // channels 16..18 (half 0) / zeros (half 1: ch >= 20)
+        t.T1.hi[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
+        t.T1.hi[4] = p01.x; t.T1.hi[5] = p01.y; t.T1.hi[6] = p23.x; t.T1.hi[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
+        return t;
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -740,16 +782,6 @@ __device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j
         for (int i = 0; i < 4; ++i) v1[4 + i] = h == 0 ? st[(RD + i) * 32 + j] : 0.f;  // dir sits at tv[24..27], owned by half 0
         t.T0 = split8(t.fv);
         t.T1 = split8(v1);
-    } else {
-        const unsigned* su = (const unsigned*)st;
-        const unsigned d01 = h == 0 ? su[(RD + 0) * 32 + j] : 0u, d23 = h == 0 ? su[(RD + 1) * 32 + j] : 0u;
-        const half2v p01 = __builtin_bit_cast(half2v, d01), p23 = __builtin_bit_cast(half2v, d23);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t.T0.hi[i] = (_Float16)t.fv[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t.T1.hi[i] = (_Float16)t.fv[8 + i];  // channels 16..19 (half 0) / zeros (half 1: ch >= 20)
-        t.T1.hi[4] = p01.x; t.T1.hi[5] = p01.y; t.T1.hi[6] = p23.x; t.T1.hi[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
-        t.T1.hi[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
     }
     return t;
 }
@@ -969,12 +1001,22 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
                 for (int c = 0; c < 3; ++c) st[(c * 4 + 2 * h + e) * 32 + j] = rgb[e][c];  // channel c*b²+sub   :337
         }
         const float* ff = (const float*)feat;
+        if constexpr (PREC == GDB_PREC_F16) {   // channel pairs as packed halves: rows 4s + 2h, + 1 (channels 8s + 4h ..), row 8 + h (16 + 2h, 17 + 2h)
+            unsigned* su = (unsigned*)st + j;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                su[(RF + 4 * s + 2 * h) * 32] = pack_h2(ff[4 * s], ff[4 * s + 1]);
+                su[(RF + 4 * s + 2 * h + 1) * 32] = pack_h2(ff[4 * s + 2], ff[4 * s + 3]);
+            }
+            su[(RF + 8 + h) * 32] = pack_h2(feat[2].x, h == 0 ? feat[2].y : 0.f);   // half 1's .y is the padding channel 19: stored as 0
+        } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) st[(RF + 8 * s + 4 * h + e) * 32 + j] = ff[4 * s + e];
         st[(RF + 16 + 2 * h) * 32 + j] = feat[2].x;           // channel 16 (half 0) / 18 (half 1)
         if (h == 0) st[(RF + 17) * 32 + j] = feat[2].y;       // channel 17; half 1's .y is the padding channel 19
+        }
         if (PREC != GDB_PREC_F16) {  // four fp32 rows; both halves computed the same code, each stores two of them
             st[(RD + 2 * h) * 32 + j] = h ? dir[2] : dir[0];
             st[(RD + 2 * h + 1) * 32 + j] = h ? dir[3] : dir[1];

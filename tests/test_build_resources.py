@@ -51,21 +51,22 @@ def test_occupancy_the_schedules_are_designed_for(usage):
     seen = set()
     for name, u in usage["gdb_fused.hip"].items():
         if ("k_render_fusedILb0ELi4E" in name or "k_render_denseILi1E" in name or "k_render_denseILi0ELi3E" in name or "k_render_denseILi2ELi3E" in name
-                or "k_render_soloILi0ELi3E" in name):   # (the last: the f16 segment-wave build c5 takes - V = 5 stages 17,280 B per wave, 9 waves per CU)
+                or "k_render_soloILi0ELi3E" in name):   # (the last: the f16 segment-wave build c5 takes - V = 5 stages 11,520 B per wave: its 12 waves per CU are set by these registers, not by LDS)
             assert u["vgprs"] <= 168 and u["waves_per_simd"] >= 3, (name, u)
             seen.add(name.split("I")[0])
     assert len(seen) >= 3, seen
 
 
 def test_staging_sizes_the_launcher_counts_on():
-    """LDS per wave (gdb_fused.hip stage_v<>): rows per view x 128 B.  f16: 27 rows (6 packed colour rows + 19 + 2 packed direction
-    rows), fp32 / split-f16: 35.  With 1280-byte LDS granules: V = 3 holds 12 waves per CU at every precision (two-wave workgroups
-    at fp32), V = 5 at f16 holds 9 (one-wave workgroups) - the numbers DESIGN.md quotes."""
+    """LDS per wave (gdb_fused.hip stage_v<>): rows per view x 128 B.  f16: 18 rows (6 packed colour rows + 10 packed rows of feature
+    channel pairs + 2 packed direction rows), fp32 / split-f16: 35.  With 1280-byte LDS granules: V = 3 holds 12 waves per CU at every
+    precision (two-wave workgroups at fp32), V = 5 at f16 holds 14 by LDS (one-wave workgroups) - so the 12 its registers allow run;
+    with fp32 feature rows (27 rows, rounds 3-4) it was 9 - the numbers DESIGN.md quotes."""
     gran, cap = 1280, 160 * 1024
     waves = lambda lds, n: n * (cap // (-(-n * lds // gran) * gran))
-    f16, f32 = 27 * 128, 35 * 128
+    f16, f32 = 18 * 128, 35 * 128
     assert max(waves(3 * f32, 1), waves(3 * f32, 2)) == 12 and waves(3 * f32, 1) == 11
     assert waves(3 * f16, 1) >= 12
-    assert waves(5 * f16, 1) == 9 and waves(5 * f32, 1) == 7
+    assert waves(5 * f16, 1) == 14 and waves(5 * 27 * 128, 1) == 9 and waves(5 * f32, 1) == 7
     src = open(os.path.join(build.CSRC, "gdb_fused.hip")).read()
-    assert "PREC == GDB_PREC_F16 ? 6 : 12" in src and "GDB_CFR" in src   # row_feat<>: the layout the arithmetic above assumes
+    assert "PREC == GDB_PREC_F16 ? 6 : 12" in src and "PREC == GDB_PREC_F16 ? 10 : GDB_CFR" in src   # row_feat<> / feat_rows<>: the layout the arithmetic above assumes
