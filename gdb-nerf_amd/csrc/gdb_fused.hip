@@ -489,7 +489,11 @@ __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off
     return ldu_pin<f32x16>(mf + off, (unsigned)h * 64u);
 }
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
+#if defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // timing experiment (wrong results): no weight loads at all
+    half8 r; asm volatile("" : "=v"(r)); return r;
+#else
     return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
+#endif
 }
 #define LANE_KEYS() const int lane_o = opaque(lane), h_o = lane_o >> 5; (void)h_o
 
