@@ -18,6 +18,7 @@ SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE, SCHED_FLAT = 0, 1
 SCHED_PLAN_READY = 0x100
 SCHED_PYR16_READY = 0x200
 PREP_PYR16 = 1
+PREP_PYR16_ONLY = 2
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8

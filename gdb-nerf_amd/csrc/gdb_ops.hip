@@ -403,13 +403,13 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
         for (int c = GDB_CF; c < GDB_CFR; ++c) v[c] = in0 ? src[(size_t)c * a.H * a.W] : 0.f;
     }
     v[GDB_CFR] = 0.f;
-    float4* pyr4 = (float4*)(a.pyr + (size_t)bv * a.pyrStride);
+    float4* pyr4 = a.pyr ? (float4*)(a.pyr + (size_t)bv * a.pyrStride) : nullptr;   // nullptr: GDB_PREP_PYR16_ONLY
     char* p16 = a.pyr16 ? a.pyr16 + (size_t)bv * 2 * a.pyrStride : nullptr;
 #pragma unroll
     for (int c = 0; c < GDB_CP / 4; ++c) {
         const float4 q = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
         tile4[(c * PT_H + ly) * PT_W + lx] = q;                           // texels outside the map are zero
-        if (in0) pyr4[((size_t)c * a.H + gy) * a.W + gx] = q;
+        if (in0 && pyr4) pyr4[((size_t)c * a.H + gy) * a.W + gx] = q;
     }
     if (p16 && in0) {  // level 0 of the half-precision copy: the texel's two 16-byte planes and its 8-byte plane, straight from registers
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
             l1[j2][i2] = box4(T[sy * PT_W + sx], T[sy * PT_W + sx + 1], T[(sy + 1) * PT_W + sx], T[(sy + 1) * PT_W + sx + 1]);
             const int px = (x0 >> 1) + 2 * bx + i2, py = (y0 >> 1) + 2 * by + j2;
             if (px < a.lvlW[1] && py < a.lvlH[1]) {
-                pyr4[(a.lvlOff[1] >> 2) + ((size_t)ch * a.lvlH[1] + py) * a.lvlW[1] + px] = l1[j2][i2];
+                if (pyr4) pyr4[(a.lvlOff[1] >> 2) + ((size_t)ch * a.lvlH[1] + py) * a.lvlW[1] + px] = l1[j2][i2];
                 if (p16) store16_chunk(p16, 2u * a.lvlOff[1], (unsigned)(a.lvlH[1] * a.lvlW[1]), (unsigned)(py * a.lvlW[1] + px), ch, l1[j2][i2]);
             }
         }
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     {
         const int px = (x0 >> 2) + bx, py = (y0 >> 2) + by;
         if (px < a.lvlW[2] && py < a.lvlH[2]) {
-            pyr4[(a.lvlOff[2] >> 2) + ((size_t)ch * a.lvlH[2] + py) * a.lvlW[2] + px] = l2;
+            if (pyr4) pyr4[(a.lvlOff[2] >> 2) + ((size_t)ch * a.lvlH[2] + py) * a.lvlW[2] + px] = l2;
             if (p16) store16_chunk(p16, 2u * a.lvlOff[2], (unsigned)(a.lvlH[2] * a.lvlW[2]), (unsigned)(py * a.lvlW[2] + px), ch, l2);
         }
     }
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
         const float4 l3 = box4(l2, nb, nc, nd);
         const int px = (x0 >> 3) + (bx >> 1), py = y0 >> 3;
         if (px < a.lvlW[3] && py < a.lvlH[3]) {
-            pyr4[(a.lvlOff[3] >> 2) + ((size_t)ch * a.lvlH[3] + py) * a.lvlW[3] + px] = l3;
+            if (pyr4) pyr4[(a.lvlOff[3] >> 2) + ((size_t)ch * a.lvlH[3] + py) * a.lvlW[3] + px] = l3;
             if (p16) store16_chunk(p16, 2u * a.lvlOff[3], (unsigned)(a.lvlH[3] * a.lvlW[3]), (unsigned)(py * a.lvlW[3] + px), ch, l3);
         }
     }
@@ -517,7 +517,8 @@ extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, si
 }
 
 extern "C" int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, int32_t flags, void* ws, size_t ws_bytes, void* stream_) {
-    if (flags & ~GDB_PREP_PYR16) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: unknown flag bits 0x%x", (unsigned)(flags & ~GDB_PREP_PYR16));
+    if (flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: unknown flag bits 0x%x", (unsigned)(flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)));
+    if ((flags & GDB_PREP_PYR16_ONLY) && !(flags & GDB_PREP_PYR16)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: GDB_PREP_PYR16_ONLY needs GDB_PREP_PYR16");
     if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex with d_fpn_feat resamples frame->d_src_images: it is NULL");
     return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_);
 }
@@ -549,6 +550,7 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     a.pyrStride = (unsigned)L.pyrStride;
     a.img_feat = fpn_feat ? fpn_feat : f->d_img_feat; a.pyr = (float*)((char*)ws + L.pyrOff);
     a.pyr16 = (flags & GDB_PREP_PYR16) ? (char*)ws + L.pyr16Off : nullptr;
+    if (flags & GDB_PREP_PYR16_ONLY) a.pyr = nullptr;   // the fp32 pyramid is not written
     // the half-precision copy is addressed with 32-bit byte offsets inside one (batch, view) block
     if (a.pyr16 && (size_t)2 * L.pyrStride >= ((size_t)1 << 32)) return gdb_fail(GDB_E_SHAPE, "feature map too large for the half-precision pyramid");
     a.fpn = fpn_feat != nullptr; a.src_images = f->d_src_images; a.Ho = f->Ho; a.Wo = f->Wo;

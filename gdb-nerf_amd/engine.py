@@ -91,6 +91,9 @@ class HotPathEngine:
         self._ws: Optional[torch.Tensor] = None
         self._plan_key = None
         self._pyr16_ready = False
+        self._pyr32_ready = True
+        self._fpn_ptr = None
+        self.f16_only_prepare = True   # a PREC_F16 engine's prepare() writes the half-precision pyramid alone (see prepare)
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
         self.reuse_outputs = False
@@ -211,14 +214,31 @@ class HotPathEngine:
                               f"nerf.max_mipmap_level = {self.cfg.max_mipmap_level}; footprints are clamped to that level")
         # an engine whose precision is PREC_F16 has the half-precision copy of the pyramid written in the same launch (the f16 render
         # gathers from it); any other engine that is asked for an f16 render later lets that render convert the fp32 pyramid itself
+        # ... and ONLY that copy (`f16_only_prepare`, default on): the fp32 pyramid is 26 of k_prepare's 58 MB of traffic at the DTU
+        # size and an f16 render never reads it.  Whatever does read it later on this frame - an f32 / split-f16 render, the
+        # operator mirror encode(), feature_pyramid() - goes through _need_pyr32(), which prepares again in full first.
         self._pyr16_ready = False
+        self._pyr32_ready = False
+        self._fpn_ptr = None if fpn is None else fpn.data_ptr()
         flags = _lib.PREP_PYR16 if (self.precision == _lib.PREC_F16 and "src_images" in frame) else 0
-        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), None if fpn is None else fpn.data_ptr(), flags,
+        if flags and self.f16_only_prepare:
+            flags |= _lib.PREP_PYR16_ONLY
+        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags,
                                            self._ws.data_ptr(), self._ws.numel(), self._stream()))
-        self._pyr16_ready = bool(flags)
+        self._pyr16_ready = bool(flags & _lib.PREP_PYR16)
+        self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
             self._plan_key = self._prior_key(frame.get("depth_range"))
         return self.mip_levels
+
+    def _need_pyr32(self) -> None:
+        """The fp32 feature pyramid of the frame last prepared, built now if that prepare wrote the half-precision copy alone."""
+        if getattr(self, "_pyr32_ready", True) or self._frame is None:
+            return
+        flags = _lib.PREP_PYR16 if self._pyr16_ready else 0
+        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(self._frame), self._fpn_ptr, flags,
+                                           self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        self._pyr32_ready = True
 
     @staticmethod
     def _prior_key(dr: Optional[torch.Tensor]):
@@ -341,6 +361,7 @@ class HotPathEngine:
         """The mip pyramid `prepare` built, as nvdiffrast would hold it: a list over levels of
         (B, V, H_l, W_l, C_f+3) tensors (copies; the workspace keeps the chunk-planar layout)."""
         f = self._need_frame()
+        self._need_pyr32()
         out = (C.c_size_t * 7)()
         _lib.check(self.lib.gdb_pyramid_layout(C.byref(self.cfg), C.byref(f), out))
         off, stride, levels = out[0], out[1], out[2]
@@ -445,6 +466,7 @@ class HotPathEngine:
     def encode(self, rays_xyz: torch.Tensor, uvd: torch.Tensor, ball_radii: torch.Tensor,
                samples_per_batch: torch.Tensor, total: torch.Tensor):
         f = self._need_frame()
+        self._need_pyr32()
         n = rays_xyz.shape[0]
         bb = self.b * self.b
         _chk(rays_xyz, "rays_xyz", (n, 3, bb)); _chk(uvd, "uvd", (n, 3)); _chk(ball_radii, "ball_radii", (n,))
@@ -531,6 +553,8 @@ class HotPathEngine:
         f = self._need_frame()
         row_end = f.H if row_end is None else row_end
         precision = self.precision if precision is None else precision
+        if precision != _lib.PREC_F16:
+            self._need_pyr32()
         nb = self.n_bundles
         if out is None:
             if row_begin == 0 and row_end == f.H:  # every row is written: a reused buffer needs no zero-fill
@@ -556,6 +580,8 @@ class HotPathEngine:
         f = self._need_frame()
         row_end = f.H if row_end is None else row_end
         precision = self.precision if precision is None else precision
+        if precision != _lib.PREC_F16:
+            self._need_pyr32()
         nb = self.n_bundles
         if out is None:
             full = row_begin == 0 and row_end == f.H

@@ -149,8 +149,13 @@ int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_
  *                   load instructions instead of three; values = the fp32 pyramid's, rounded to nearest half once, every mip level
  *                   box-filtered in fp32 first).  Replaces nothing of the reference: nvdiffrast rebuilds its fp32 mip stack inside
  *                   every texture() call (bundle_sampler.py:355-359); this is a second, narrower copy for the opt-in fast path.
- *                   Pass GDB_SCHED_PYR16_READY to the render calls of this frame. */
+ *                   Pass GDB_SCHED_PYR16_READY to the render calls of this frame.
+ *   GDB_PREP_PYR16_ONLY  (with GDB_PREP_PYR16) write ONLY the half-precision pyramid: the fp32 pyramid in the workspace is left as
+ *                   it was (26 of the 58 MB k_prepare moves at 512x640, V = 3).  Only GDB_PREC_F16 fused renders may follow; gdb_encode, the
+ *                   f32 / split-f16 renders and gdb_build_pyr16 read the fp32 pyramid and need a prepare without this flag first
+ *                   (like GDB_SCHED_PLAN_READY this is the caller's promise: the library keeps no state to check it against). */
 #define GDB_PREP_PYR16 1
+#define GDB_PREP_PYR16_ONLY 2
 int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, void* d_workspace,
                    size_t workspace_bytes, void* stream);
 

@@ -17,7 +17,9 @@ import torch
 
 import gdb_oracle as oracle
 from conftest import FRAME_KEYS, frame_of, load_golden, max_abs, nerf_weights_of
-from gdb_nerf_amd import synthetic
+import ctypes as C
+
+from gdb_nerf_amd import _lib, synthetic
 from gdb_nerf_amd.engine import HotPathEngine
 
 pytestmark = pytest.mark.gpu
@@ -142,6 +144,40 @@ def test_half_precision_pyramid_is_the_fp32_one_rounded_once(Ho, Wo, V, B, level
             assert np.array_equal(npy(a[l][bi]).view(np.uint16), h16.view(np.uint16)), (bi, l, "k_prepare")
             assert np.array_equal(npy(b[l][bi]).view(np.uint16), h16.view(np.uint16)), (bi, l, "k_pyr16")
     assert torch.equal(eng.render()[0], r16)           # both routes render the same image, bit for bit
+
+
+def test_f16_engine_prepares_the_half_precision_pyramid_alone():
+    """gdb_prepare_ex(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY), what a PREC_F16 engine's prepare() asks for: the fp32 pyramid in the
+    workspace is NOT written (a sentinel survives), the half-precision copy and the f16 render are bit-identical to the engine that
+    writes both, and whatever needs the fp32 pyramid later on the same frame (an f32 render, feature_pyramid(), the operator mirror
+    encode() inside render_unfused()) gets it through a second, full prepare.  The flag alone is rejected."""
+    frame = synthetic.make_frame(96, 128, V=3, B=2, seed=4)
+    w = synthetic.make_nerf_weights(seed=2)
+    both = HotPathEngine(is_adaptive=True); both.precision = 0; both.f16_only_prepare = False; both.load_weights(w)
+    only = HotPathEngine(is_adaptive=True); only.precision = 0; only.load_weights(w)
+    fr = dev_frame(frame)
+    both.prepare(fr); only.prepare(fr)                                   # (sizes the workspace)
+    lay = (C.c_size_t * 7)()
+    _lib.check(only.lib.gdb_pyramid_layout(C.byref(only.cfg), C.byref(only._frame), lay))
+    n32 = 4 * int(lay[1]) * only._frame.B * only._frame.V
+    only._ws[int(lay[0]):int(lay[0]) + n32].fill_(0xA5)                   # sentinel over the whole fp32 pyramid
+    only.prepare(fr)
+    assert only._pyr16_ready and not only._pyr32_ready and both._pyr32_ready
+    assert bool((only._ws[int(lay[0]):int(lay[0]) + n32] == 0xA5).all())  # untouched
+    for a, b in zip(only.feature_pyramid16(), both.feature_pyramid16()):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert torch.equal(only.render()[0], both.render()[0])
+    assert not only._pyr32_ready                                         # an f16 render does not need it
+    r32 = only.render(precision=1)[0].clone()                            # ... an f32 render does: full prepare first
+    assert only._pyr32_ready
+    assert torch.equal(r32, both.render(precision=1)[0])
+    for a, b in zip(only.feature_pyramid(), both.feature_pyramid()):
+        assert torch.equal(a, b)
+    only.prepare(fr)
+    assert not only._pyr32_ready
+    assert torch.equal(only.render_unfused()[0], both.render_unfused()[0]) and only._pyr32_ready
+    rc = only.lib.gdb_prepare_ex(C.byref(only.cfg), C.byref(only._frame), None, _lib.PREP_PYR16_ONLY, only._ws.data_ptr(), only._ws.numel(), None)
+    assert rc != 0 and "GDB_PREP_PYR16" in only.lib.gdb_last_error().decode()
 
 
 @pytest.mark.parametrize("tag", ["dtu", "nerfinv", "mips"])
