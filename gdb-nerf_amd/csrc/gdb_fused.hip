@@ -2717,7 +2717,8 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
         if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_flat: %s", hipGetErrorString(e));
         return GDB_OK;
     }
-    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && dense_fits);
+    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && dense_fits &&
+                            (cfg->is_adaptive || (PREC != GDB_PREC_F16 && gdb_fixed_counts_dense(*cfg, V))));
     if (want_dense && solo_lds <= lds_max) {
         if (!dense_fits) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
         // The plan + sample list are built here, into the plan region of the caller's workspace (a launch of its own on the same

@@ -560,10 +560,11 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
     a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff); a.nsamp = (int*)((char*)ws + L.nsampOff);
-    // Built here (inside this launch, ~1 us) for adaptive configs whenever the frame carries its depth prior: a render call that
+    // Built here (inside this launch, ~1 us) for adaptive configs (and the fixed-count ones the dense schedule takes:
+    // gdb_fixed_counts_dense) whenever the frame carries its depth prior: a render call that
     // is told so (GDB_SCHED_PLAN_READY) uses it as it stands; any other dense render builds the plan itself (gdb_build_dense_plan,
     // a launch of its own on the same stream).
-    a.nplan = (f->d_depth_range && cfg->is_adaptive) ? (f->B * f->H + 3) / 4 : 0;
+    a.nplan = (f->d_depth_range && (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, f->V))) ? (f->B * f->H + 3) / 4 : 0;
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;

@@ -92,6 +92,7 @@ class HotPathEngine:
         self._plan_key = None
         self._pyr16_ready = False
         self._pyr32_ready = True
+        self._plan_static = False
         self._fpn_ptr = None
         self.f16_only_prepare = True   # a PREC_F16 engine's prepare() writes the half-precision pyramid alone (see prepare)
         self.schedule = _lib.SCHED_AUTO
@@ -229,6 +230,8 @@ class HotPathEngine:
         self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
             self._plan_key = self._prior_key(frame.get("depth_range"))
+        self._plan_static = (not self.cfg.is_adaptive and self.cfg.max_num_samples > 3 and V <= 3 and "depth_range" in frame
+                             and "src_images" in frame)
         return self.mip_levels
 
     def _need_pyr32(self) -> None:
@@ -426,6 +429,8 @@ class HotPathEngine:
         """The schedule argument of a render call: this engine's schedule, plus the plan-is-current flag while the depth prior
         the last prepare() consumed is untouched."""
         ready = self._plan_key is not None and self._prior_key(self._keep.get("depth_range")) == self._plan_key
+        if not self.cfg.is_adaptive:   # fixed counts: the plan gdb_prepare built (gdb_fixed_counts_dense) does not depend on the prior's values
+            ready = self._plan_static
         return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0) | (_lib.SCHED_PYR16_READY if self._pyr16_ready else 0)
 
     @property
