@@ -257,6 +257,18 @@ __device__ void plan_row(const PrepArgs& a, int rowid, int lane, unsigned* __res
     const float* farp = nearp + hw;
     int* rec = a.plan + (size_t)rowid * (a.planMW + 2);
     unsigned* sm = a.smap + (size_t)rowid * a.smapStride;
+    if (!a.adaptive) {
+        // Fixed counts (gdb_fixed_counts_dense): every bundle holds S_max samples, so the plan is closed-form - windows of floor(32 /
+        // S_max) whole bundles, the best any cut can do - and needs neither the depth prior nor the chain (which made k_prepare 30 us
+        // longer at S_max 8: 2,560 sample offsets per row, 80 hops).
+        const int S = a.S_max, bpw = max(32 / S, 1), nwin = (a.W + bpw - 1) / bpw, total = a.W * S;
+        for (int x = lane; x < a.W; x += 64)
+            for (int k = 0; k < S; ++k) sm[x * S + k] = (unsigned)x | ((unsigned)k << 16) | ((unsigned)S << 24);
+        for (int e = total + lane; e < a.smapStride; e += 64) sm[e] = 0xFFFFFFFFu;
+        for (int w = lane; w < nwin; w += 64) rec[1 + w] = w * bpw * S;
+        if (lane == 0) { rec[0] = nwin; rec[1 + nwin] = total; a.nwin[rowid] = nwin; a.nsamp[rowid] = total; }
+        return;
+    }
     // The greedy chain costs ~0.1 us per window of the row on k_prepare's critical path (c2: +2.5 us) and saves idle lanes in the
     // render (c2, 960 sample offsets per row, S_max 3: 1 us; c3, 1440: 9 us; c4, 2400, S_max 6: 23 us): taken from 1024 offsets up.
     const bool greedy = a.W * a.S_max < PLAN_LDS_ROW && a.W * a.S_max >= PLAN_GREEDY_MIN;

@@ -612,13 +612,14 @@ def test_split_f16_small_operands_have_an_absolute_floor(wscale, bound):
 
 
 @pytest.mark.parametrize("Ho,Wo,B,S,adaptive,inv,scene", [(32, 48, 2, 3, True, False, "dtu"), (64, 80, 1, 3, True, False, "dtu"), (96, 72, 2, 6, True, True, "nerf"),
-                                                          (32, 64, 1, 16, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu"),
+                                                          (32, 64, 1, 16, False, False, "dtu"), (64, 80, 2, 6, False, False, "dtu"), (40, 330, 1, 5, True, False, "llff"), (512, 640, 1, 3, True, False, "dtu"),
                                                           (8, 800, 1, 16, True, False, "dtu"), (16, 960, 1, 3, True, False, "llff"), (8, 800, 1, 6, True, False, "nerf")])
 def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
     """The plan of the dense schedule (plan_row): for every bundle-map row the compacted sample list is the reference's
     (bundle_sampler.py:182-189: bundle-major, sample-minor, from the oracle's per-bundle counts), and the windows cut it into
     consecutive runs of WHOLE bundles of at most 32 samples that cover the row - greedily (a window ends only where the next
-    bundle would not fit) on rows of 1024 .. 4095 sample offsets (W * S_max), at fixed offsets L * w on shorter and longer ones."""
+    bundle would not fit) on rows of 1024 .. 4095 sample offsets (W * S_max), at fixed offsets L * w on shorter and longer ones;
+    fixed counts: windows of floor(32 / S_max) bundles."""
     frame = synthetic.make_frame(Ho, Wo, V=2, B=B, scene=scene, seed=17)
     eng = engine_for(frame, synthetic.make_nerf_weights(seed=1), (3, 0), max_num_samples=S, is_adaptive=adaptive, inv_depth=inv)
     dense = [t.clone() for t in eng.render()]   # an explicit dense render builds the plan where prepare did not (fixed counts)
@@ -638,6 +639,10 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
         off = np.concatenate(([0], np.cumsum(cnt[r])))       # sample offset of every bundle's first sample, then the total
         assert np.all(np.isin(starts, off))                  # windows hold whole bundles
         nxt = {int(o): int(c) for o, c in zip(off[:-1], cnt[r])}
+        if not adaptive:   # fixed counts: closed form - windows of floor(32 / S) whole bundles (no chain, no look at the depth prior)
+            bpw = 32 // S
+            assert nwin == -(-W // bpw) and np.array_equal(starts, np.minimum(np.arange(nwin + 1) * bpw * S, tot))
+            continue
         for w in range(nwin - 1):
             if greedy:   # the bundle that opens window w + 1 did not fit into window w
                 assert starts[w + 1] - starts[w] + nxt[int(starts[w + 1])] > 32
