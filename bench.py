@@ -565,7 +565,7 @@ def main():
         flat = args.precision == "f32" and wl["S"] <= 4 and (H * W * wl["S"] + 31) // 32 + 1 <= 3 * 3072
         # (fixed counts: slot waves up to 3 samples; above that the dense schedule at fp32 / split-f16 with <= 3 views, else the segment wave:
         # gdb_fixed_counts_dense in gdb_internal.h)
-        auto = (4 if flat else 3) if wl["adaptive"] else (1 if wl["S"] <= 3 else (3 if (V <= 3 and args.precision != "f16") else 2))
+        auto = (4 if flat else 3) if wl["adaptive"] else ((3 if (wl["S"] == 2 and V <= 3 and args.precision != "f16") else 1) if wl["S"] <= 3 else (3 if (V <= 3 and args.precision != "f16") else 2))
         kname = {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[args.schedule or auto]
     else:
         kname = "k_mlp"
@@ -667,7 +667,7 @@ def main():
             km8 = hot_ms(timed, lambda: e8.render(0, H, prec, o8))
             ns8 = int(e8.sample()["total"].item())
             af8 = alg_flops(ns8, V)
-            sched8 = args.schedule or (3 if adaptive else (1 if smax <= 3 else (3 if (V <= 3 and args.precision != "f16") else 2)))   # (S_max 8: never the flat schedule under AUTO)
+            sched8 = args.schedule or (3 if adaptive else ((3 if (smax == 2 and V <= 3 and args.precision != "f16") else 1) if smax <= 3 else (3 if (V <= 3 and args.precision != "f16") else 2)))   # (S_max 8: never the flat schedule under AUTO)
             return {"S_max": smax, "sampling": "adaptive" if adaptive else "fixed", "precision": args.precision,
                     "kernel": {1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[sched8],
                     "value": Ho * Wo * k2 / dt8, "ms_per_step": dt8 / k2 * 1e3, "steps": k2, "kernel_ms": km8, "n_samples": ns8,

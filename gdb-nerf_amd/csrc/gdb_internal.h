@@ -97,11 +97,12 @@ struct WsLayout {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Fixed sample counts (is_adaptive = 0) for which GDB_SCHED_AUTO takes the DENSE schedule at fp32 / split-f16 (the sample list is then
-// S_max entries per bundle: the plan does not depend on the depth prior's values): more than 3 samples per bundle and at most 3 source
-// views.  Measured at 512x640, V = 3 (profiles/r04/ab_fixed_counts_dense_vs_solo.txt, dense / segment wave, us): fp32 S 4 162 / 177,
+// S_max entries per bundle: the plan does not depend on the depth prior's values): more than 3 samples per bundle (or exactly 2) and at
+// most 3 source views.  Measured at 512x640, V = 3 (profiles/r04/ab_fixed_counts_dense_vs_solo.txt, dense / segment wave, us): fp32 S 4 162 / 177,
 // S 6 241 / 261, S 8 284 / 347; split-f16 S 8 190 / 235; but f16 S 8 139 / 137, S 4 84 / 71, and V = 5 (c5) fp32 2,429 / 1,870.
 // gdb_prepare builds the plan for such configs too, so that a render told GDB_SCHED_PLAN_READY need not.
-static inline bool gdb_fixed_counts_dense(const GdbConfig& c, int V) { return !c.is_adaptive && c.max_num_samples > 3 && V <= 3; }
+// (S_max 2: dense 77.3 / slot waves 84.7; S_max 3 stays on the slot waves: 117.1 / dense 121.2)
+static inline bool gdb_fixed_counts_dense(const GdbConfig& c, int V) { return !c.is_adaptive && (c.max_num_samples > 3 || c.max_num_samples == 2) && V <= 3; }
 
 
 static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {

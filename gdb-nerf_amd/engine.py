@@ -230,7 +230,7 @@ class HotPathEngine:
         self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
             self._plan_key = self._prior_key(frame.get("depth_range"))
-        self._plan_static = (not self.cfg.is_adaptive and self.cfg.max_num_samples > 3 and V <= 3 and "depth_range" in frame
+        self._plan_static = (not self.cfg.is_adaptive and (self.cfg.max_num_samples > 3 or self.cfg.max_num_samples == 2) and V <= 3 and "depth_range" in frame
                              and "src_images" in frame)
         return self.mip_levels
 

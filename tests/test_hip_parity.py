@@ -664,7 +664,7 @@ def test_dense_plan_invariants(Ho, Wo, B, S, adaptive, inv, scene):
         assert max_abs(npy(a), npy(b)) <= 2e-5 * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("V,S,prec,dense", [(3, 6, 1, True), (2, 8, 2, True), (3, 6, 0, False), (4, 6, 1, False), (3, 3, 1, False)])
+@pytest.mark.parametrize("V,S,prec,dense", [(3, 6, 1, True), (2, 8, 2, True), (3, 6, 0, False), (4, 6, 1, False), (3, 3, 1, False), (3, 2, 1, True)])
 def test_auto_schedule_for_fixed_counts(V, S, prec, dense):
     """GDB_SCHED_AUTO with fixed sample counts (gdb_fixed_counts_dense): more than 3 samples per bundle and at most 3 views render on
     the dense schedule at fp32 / split-f16 - bit-identical to an explicit GDB_SCHED_DENSE, its plan built by gdb_prepare (closed
@@ -673,13 +673,13 @@ def test_auto_schedule_for_fixed_counts(V, S, prec, dense):
     frame = synthetic.make_frame(64, 96, V=V, B=2, seed=31)
     w = synthetic.make_nerf_weights(seed=3)
     auto = engine_for(frame, w, (0, prec), max_num_samples=S, is_adaptive=False)
-    assert bool(auto._sched() & 0x100) == (S > 3 and V <= 3)            # the plan is there whenever the rule may take it
+    assert bool(auto._sched() & 0x100) == ((S > 3 or S == 2) and V <= 3)            # the plan is there whenever the rule may take it
     a = [t.clone() for t in auto.render()]
     other = engine_for(frame, w, (3 if dense else (2 if S > 3 else 1), prec), max_num_samples=S, is_adaptive=False)
     for x, y in zip(a, other.render()):
         assert torch.equal(x, y)
-    if S > 3 and V <= 3:
-        flip = engine_for(frame, w, (2 if dense else 3, prec), max_num_samples=S, is_adaptive=False)
+    if (S > 3 or S == 2) and V <= 3:
+        flip = engine_for(frame, w, ((2 if S > 3 else 1) if dense else 3, prec), max_num_samples=S, is_adaptive=False)
         assert not torch.equal(a[0], flip.render()[0])                  # (the two schedules differ in the last bits: AUTO really took `other`)
     ref = auto.render_unfused()
     tol = {0: 2e-3, 1: 5e-4, 2: 5e-4}[prec]
