@@ -15,10 +15,12 @@ triad and bare MFMA loops run on this node), `t_frame_ms` (whole Network.forward
 protocol), `roofline` and `cpu_baseline`.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU), both modes timed in one run:
-  rows   (headline, north_star's partitioning, strong scaling): ONE frame, bundle-map row strips over the ranks,
-         packed (n_bundles, 41) output, a single RCCL all-gather of the strips; `allgather_ms` and bus GB/s reported.
-  frames (the `independent_frames` record, weak scaling): every rank renders its own frame (independent target
-         views, as an evaluation sweep does); no data-path collective.
+  frames (headline since round 4, weak scaling): every rank renders its own frame (independent target views, as an evaluation
+         sweep does) - the path partitions into independent units, so no data-path collective; `value` = rays of all ranks / time.
+  rows   (the `single_frame_rows` record, north_star's partitioning of ONE frame, strong scaling): bundle-map row strips over the
+         ranks, packed (n_bundles, 41) output, a single RCCL all-gather of the strips; `allgather_ms` and bus GB/s reported, the
+         gathered strips checked bit for bit against a full render.  At 512x640 a frame is ~0.1 ms of work: the split is
+         latency-bound by the all-gather (13.4 MB) and is the latency mode, not the throughput mode.  `--shard rows` makes it the headline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -362,7 +364,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"], help="arithmetic of the NeRF MLP in the fused kernel")
     ap.add_argument("--schedule", type=int, default=0, choices=[0, 1, 2, 3, 4], help="GDB_SCHED_*: 0 auto, 1 slot waves, 2 segment wave, 3 dense, 4 flat")
     ap.add_argument("--path", default="fused", choices=["fused", "unfused"])
-    ap.add_argument("--shard", default="rows", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
+    ap.add_argument("--shard", default="frames", choices=["rows", "frames"], help="N > 1: which mode is the headline (both are timed)")
     ap.add_argument("--frame-ring", type=int, default=0,
                     help="number of distinct device copies of the input frame the steps cycle through (0 = as many as it takes to "
                          "exceed the 256 MiB Infinity Cache, at most 8): consecutive steps then read their inputs from HBM, not from cache")
@@ -549,6 +551,7 @@ def main():
         else:
             dt, rays_per_step, share = dt_frames, world * Ho * Wo, 1.0
             extra["single_frame_rows"] = rec_rows
+            extra.update({"world_size": world, "gathered_equals_full_render": rows_ok})
             kern_ms_override = kern_frames
 
     kern_ms = (kern_fused_ms if kern_fused_ms is not None else ev_ms(kern_pairs)) if world == 1 else kern_ms_override

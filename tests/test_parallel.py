@@ -257,8 +257,8 @@ def test_bench_self_launches_its_ranks():
 def test_bench_two_ranks_self_launched_on_one_gpu():
     """The same command form on the GPU box: `python bench.py --gpus 2` starts two ranks that share the one card (GDB_BENCH_REHEARSE=1:
     gloo, the all-gather staged through host memory - a rehearsal of the product path, never a measurement).  The line must carry
-    what an N > 1 record is graded on: both modes, the gathered strips equal to the full render, every rank's kernel time and
-    roofline fraction, and rank 0's CPU baseline."""
+    what an N > 1 record is graded on: both modes (headline: independent frames, weak scaling), the gathered strips equal to the
+    full render, every rank's kernel time and roofline fraction, and rank 0's CPU baseline."""
     import json
     import subprocess
     import sys
@@ -271,9 +271,18 @@ def test_bench_two_ranks_self_launched_on_one_gpu():
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
-    assert rec["gathered_equals_full_render"] is True and "independent_frames" in rec
+    # headline = every rank its own frame (weak scaling, no data-path collective); the one-frame row split + all-gather rides along
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    rows = rec["single_frame_rows"]
+    assert rec["gathered_equals_full_render"] is True and rows["gathered_equals_full_render"] is True and rows["scaling"] == "strong"
+    assert rows["allgather_bytes_per_rank"] > 0 and rows["value"] > 0 and rec["config"]["shard"] == "frames"
     assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1]
     assert all(r["kernel_ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in rec["per_rank"])
-    assert rec["per_rank"][0]["rows"] == [0, 128] and rec["per_rank"][1]["rows"] == [128, 256]
+    assert rec["per_rank"][0]["rows"] == [0, 128] and rec["per_rank"][1]["rows"] == [128, 256]   # (the strips of the rows record)
+    # ... and `--shard rows` puts the strong-scaling record on top
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50", "--shard", "rows", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec2 = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert rec2["scaling"] == "strong" and rec2["gathered_equals_full_render"] is True and "independent_frames" in rec2
     assert rec["cpu_baseline"]["cores"] == 8 and rec["cpu_baseline"]["value"] > 0
