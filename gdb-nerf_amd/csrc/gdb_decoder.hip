@@ -189,7 +189,9 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
 // global residual), Y = [x1 | x2] of the block in flight, T = conv3's output; the dense block's torch.cat([x, x1, x2]) is "chunks 0-1
 // from P[b], chunks 2-3 from Y".  part = per-(row, 32-pixel segment) channel sums of T (written by conv3's epilogue), part2 = their
 // sums per group of DEC_SEG segments, gate = the block's 64 gates per batch item, count = one arrival counter per batch item.
-#define DEC_SEG 64   // segments per workgroup of k_se_gate's first stage
+#ifndef DEC_SEG
+#define DEC_SEG 128   // segments per workgroup of k_se_gate's first stage (256x320, 2,560 segments: 16 / 32 / 64 / 128 / 256 -> 18.4 / 10.8 / 7.9 / 6.6 / 7.8 us: the last arriver's serial tail)
+#endif
 struct DecWs { size_t P[3], Y, T, part, part2, gate, count, total; int nseg, ngrp; };
 static DecWs dec_ws(int B, int H, int W) {
     DecWs w{};
