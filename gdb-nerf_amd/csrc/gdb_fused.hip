@@ -2407,8 +2407,11 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
 // right-nested (S_max <= 4: the Horner chain) or by doubling (S_max > 4: the ds_bpermute steps).
 // NS = slots unrolled (registers, all records requested up front: one memory round trip behind the header's): 4 for S_max <= 4, 16 else.
 // One wave takes FIX_PER_WAVE consecutive boundaries, all their records requested before the first is used (the kernel is a launch
-// ramp and two dependent memory round trips long, not arithmetic: fewer, fatter waves).
-#define FIX_PER_WAVE 4
+// ramp and two dependent memory round trips long, not arithmetic).  Measured again on the final kernels (same box, c2 fp32, render /
+// prepare + render on the HBM ring, us): 1 per wave 94.0 / 107.6, 2: 94.5 / 108.2, 3: 94.9 / 108.7, 4: 95.5 / 109.3, 8: 96.8.
+#ifndef FIX_PER_WAVE
+#define FIX_PER_WAVE 1
+#endif
 template <int NS>
 __global__ void __launch_bounds__(256) k_flat_fix(FusedArgs a) {
 #pragma clang fp contract(off)
