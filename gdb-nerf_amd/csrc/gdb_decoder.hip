@@ -44,12 +44,10 @@ typedef unsigned U2 __attribute__((ext_vector_type(2)));
 
 #define DEC_NF 64    // num_feats (network.py:51)
 #define DEC_G 32     // growth rate (decoder_rdn.py:27)
-#define DEC_CS 128   // channel stride of the dense-block buffer [x | x1 | x2]
 #define DEC_PX 34    // pixels per staged row: 32 + halo
 #define DEC_CHS 34   // floats per staged pixel: 32 channels of the chunk + 2 (bank spread for the 8-byte reads)
 #define DECX_PXD 20  // split-f16 staging: dwords per pixel = 8 (hi halves of a chunk's 16 channels) + 8 (lo halves) + 4 (bank spread for the 16-byte reads)
 #define DEC_SE_R 4   // SE bottleneck: 64 / 16
-#define DEC_RED 256  // pixels per block of the channel-mean's first stage (a 256x320 map: 320 blocks; 4096 gave 20 blocks = 246 us)
 
 // ---- packed weights -------------------------------------------------------------------------------------------------
 // conv_floats(cin, nt): floats of a packed layer of 32 nt output channels (fp32 form pack_conv16 and split-f16 form pack_conv_x alike).
