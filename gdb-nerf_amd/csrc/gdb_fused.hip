@@ -2568,7 +2568,9 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
         // 216.6 / 209.8.  The walk saves the dispatcher's gap between two tiles of a wave slot; the dispatcher's dynamic order balances
         // the long S_max 3 frames better than a static stride.  Rule fitted to those rows: the walk while the worst case is at most
         // three tiles per resident wave, or when S_max > 4.
-        bool persist = tiles <= 3 * grid * NWG || a.f.S_max > 4;
+        // (Round 4, with the walk's wave priorities in place - profiles/r04/ab_walk_vs_one_tile.txt, second table: the walk now wins on the
+        // long S_max 3 frames too: c3 fp32 174.9 / 176.2, c3' 210.4 / 211.0, c3 f16 87.8 / 93.8, split-f16 115.7 / 120.5 - always the walk.)
+        bool persist = true;
 #ifdef GDB_DIAG
         static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
         if (env_persist >= 0) persist = env_persist != 0;
