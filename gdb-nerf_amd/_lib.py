@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # GDB_NERF_LIB selects another build of the same ABI (tools/: the -DGDB_DIAG diagnostic library and A/B flag variants are
 # built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE, SCHED_FLAT = 0, 1, 2, 3, 4
 SCHED_PLAN_READY = 0x100
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "gdb_prepare": (C.c_int, [_CFG, _FRM, _P, C.c_size_t, _P]),
     "gdb_prepare_fpn": (C.c_int, [_CFG, _FRM, _P, _P, C.c_size_t, _P]),
     "gdb_prepare_ex": (C.c_int, [_CFG, _FRM, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "gdb_prepare_rows": (C.c_int, [_CFG, _FRM, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     "gdb_pyramid16_layout": (C.c_int, [_CFG, _FRM, C.POINTER(C.c_size_t)]),
     "gdb_build_rays": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P]),
     "gdb_sample": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -68,6 +69,7 @@ _SIGNATURES = {
     "gdb_depth_regression": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
     "gdb_render_bundles_fused": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gdb_render_bundles_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "gdb_render_info": (C.c_int, [_CFG, _FRM, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "gdb_merge": (C.c_int, [_CFG, _FRM, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "gdb_merge_packed": (C.c_int, [_CFG, _FRM, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "gdb_decoder_packed_floats": (C.c_int, [_CFG, C.c_int32, C.POINTER(C.c_size_t)]),

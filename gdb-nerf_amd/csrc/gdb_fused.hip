@@ -21,6 +21,9 @@
 //                weighted sum run per bundle; the (N_b, 39) output rows are written as one
 //                contiguous run per segment.
 #include "gdb_internal.h"
+#if !defined(GDB_DIAG) && (defined(GDB_XP_NOW) || defined(GDB_XP_PK))
+#error "GDB_XP_* timing experiments produce wrong results by design: they exist in the diagnostic build (-DGDB_DIAG) only"
+#endif
 #include <cstdlib>
 #include <type_traits>
 #include <cstring>
@@ -421,7 +424,6 @@ struct FusedArgs {
     int wave_floats;  // dense schedule: floats of LDS per wave (a workgroup may hold two waves, each with its own area)
     int row_lo, row_hi, tile_stride;  // dense schedule: global rows (batch item x H + row) of this launch; tiles a wave skips per step
     int flat_base;    // flat schedule: index of this launch's first window boundary in the side buffers (one launch per batch item)
-    int flat_last;    // flat schedule: the launch's last boundary in the worst case (every bundle at S_max): what k_flat_fix is launched for
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     unsigned* dbg;    // diagnostic build only
 };
@@ -489,7 +491,7 @@ __device__ __forceinline__ f32x16 load_tab(const float* __restrict__ mf, int off
     return ldu_pin<f32x16>(mf + off, (unsigned)h * 64u);
 }
 __device__ __forceinline__ half8 load_frag(const float* __restrict__ mf, int idx, int lane) {
-#if defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // timing experiment (wrong results): no weight loads at all
+#if defined(GDB_DIAG) && defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // diagnostic build only - timing experiment (wrong results): no weight loads at all
     half8 r; asm volatile("" : "=v"(r)); return r;
 #else
     return ldu_pin<half8>(mf + (size_t)idx * 256, (unsigned)lane * 16u);
@@ -576,14 +578,30 @@ __device__ __forceinline__ void fnormalize3(const float a[3], float o[3]) {
     o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
 }
 
+// ---- every fusion of the gather's coordinate arithmetic is SPELLED OUT ------------------------------------------------------------------
+// This translation unit is built with -ffp-contract=fast: where the source leaves a*b + c to the compiler, whether it becomes one fma or
+// two roundings is decided per kernel instantiation, by the code around it.  For the coordinates that is not harmless at GDB_PREC_F16:
+// an ulp of difference in a mip level moves a tap weight by 1e-7, and where the tap sum sits next to a rounding boundary its staged
+// HALF flips - one f16 ulp (1e-4) of one feature of one sample, seen as 2.7e-5 between two schedules of the same frame (round 5, when
+// the dense and flat kernels became one body).  So the functions between a sample's position and its tap weights run with contraction
+// off and say fmaf where a fused multiply-add is meant: every kernel then computes the same bits.
+__device__ __forceinline__ void tex_coord_f(float u, int size, int& i0, int& i1, float& f) {
+#pragma clang fp contract(off)
+    float x = fminf(fmaxf(fmaf(u, (float)size, -0.5f), 0.f), (float)(size - 1));
+    float xf = floorf(x);
+    i0 = (int)xf;
+    i1 = min(i0 + 1, size - 1);
+    f = x - xf;
+}
 // Bilinear taps of one mip level of the chunk-planar pyramid ([chunk][y][x] of 16-byte chunks): byte offsets of
 // the four taps inside chunk plane 0 (level offset lvlB included), the plane size in bytes, and weights;
 // clamp-to-edge.  lw scales the level's weights.
 struct Taps { unsigned o00, o10, o01, o11, planeB; float w00, w10, w01, w11; };  // byte offsets inside chunk plane 0; bytes per chunk plane
 __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsigned lvlB, float lw) {
+#pragma clang fp contract(off)
     int x0, x1, y0, y1; float fx, fy;
-    tex_coord(u, W, x0, x1, fx);
-    tex_coord(v, H, y0, y1, fy);
+    tex_coord_f(u, W, x0, x1, fx);
+    tex_coord_f(v, H, y0, y1, fy);
     Taps t;
     // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): rows and widths are far below 2^24
     unsigned r0 = __umul24(y0, W), r1 = __umul24(y1, W);
@@ -595,7 +613,7 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, unsign
     return t;
 }
 __device__ __forceinline__ void tap_acc(float4& o, const float4 a, float w) {
-#ifdef GDB_XP_PK  // Reproducer kept in-tree (tools/ab_flags.sh "-DGDB_XP_PK=1" "-DGDB_XP_PK=2"; profiles/r02/ab_packed_f32_scratch_vs_registers.txt).
+#if defined(GDB_DIAG) && defined(GDB_XP_PK)  // diagnostic build only.  Reproducer kept in-tree (tools/ab_flags.sh "-DGDB_XP_PK=1" "-DGDB_XP_PK=2"; profiles/r02/ab_packed_f32_scratch_vs_registers.txt).
     // The "packed f32 corrupts lanes 48..63" finding of round 1 is NOT a packed-math hazard: with the tap accumulate written as
     // two v_pk_fma_f32, hipcc stops promoting the Taps / RgbTaps weight structs to registers and forms the op_sel operand pairs
     // (w00,w10) (w10,w01) (w01,w11) with overlapping, 4-byte-aligned scratch_load_dwordx2 of the struct in PRIVATE MEMORY, right
@@ -646,47 +664,8 @@ __device__ __forceinline__ void taps_acc(const Taps& t, const TapData& d, float4
     acc[2].y = fmaf(d.u[3].y, t.w11, fmaf(d.u[2].y, t.w01, fmaf(d.u[1].y, t.w10, ay)));
 }
 
-// ---- the same taps from the half-precision pyramid (GDB_PREC_F16; gdb_internal.h PYR16_*) -----------------------------------
-// Half h reads ONE 16-byte texel of plane h (channels 4h..4h+3 | 8+4h..8+4h+3) and ONE 4-byte pair of plane 2 (channels 16+2h,
-// 17+2h) per tap: two load instructions where the fp32 pyramid takes three, 20 bytes where it takes 40.  Products accumulate in
-// fp32 (v_fma_mix_f32 reads the half straight out of the loaded register: no conversion instruction).
+// ---- half-precision pyramid (GDB_PREC_F16; gdb_internal.h PYR16_*): the taps are gather_view16's (below) ---------------------------------
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
-struct Taps16 { unsigned p00, p10, p01, p11, lvlB, hw; float w00, w10, w01, w11; };  // texel indices, byte offset of the level, texels per plane
-__device__ __forceinline__ Taps16 make_taps16(float u, float v, int W, int H, unsigned lvlB, float lw) {
-    int x0, x1, y0, y1; float fx, fy;
-    tex_coord(u, W, x0, x1, fx);
-    tex_coord(v, H, y0, y1, fy);
-    Taps16 t;
-    const unsigned r0 = __umul24(y0, W), r1 = __umul24(y1, W);
-    t.p00 = r0 + x0; t.p10 = r0 + x1; t.p01 = r1 + x0; t.p11 = r1 + x1;
-    t.lvlB = lvlB; t.hw = __umul24(W, H);
-    const float ex = (1.f - fx) * lw, wx = fx * lw;
-    t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
-    return t;
-}
-struct TapData16 { half8v q[4]; half2v u[4]; };
-__device__ __forceinline__ void taps_load16(const void* __restrict__ pyr16, const Taps16& t, int h, TapData16& d) {
-    const unsigned b0 = t.lvlB + (h ? 16u * t.hw : 0u), b2 = t.lvlB + PYR16_PLANE2(t.hw) + 4u * (unsigned)h;
-    d.q[0] = ldu<half8v>(pyr16, b0 + 16u * t.p00); d.q[1] = ldu<half8v>(pyr16, b0 + 16u * t.p10);
-    d.q[2] = ldu<half8v>(pyr16, b0 + 16u * t.p01); d.q[3] = ldu<half8v>(pyr16, b0 + 16u * t.p11);
-    d.u[0] = ldu<half2v>(pyr16, b2 + 8u * t.p00); d.u[1] = ldu<half2v>(pyr16, b2 + 8u * t.p10);
-    d.u[2] = ldu<half2v>(pyr16, b2 + 8u * t.p01); d.u[3] = ldu<half2v>(pyr16, b2 + 8u * t.p11);
-}
-template <bool INIT>
-__device__ __forceinline__ void taps_acc16(const Taps16& t, const TapData16& d, float4 acc[3]) {
-    const float w[4] = {t.w00, t.w10, t.w01, t.w11};
-    float* a0 = (float*)&acc[0]; float* a1 = (float*)&acc[1];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a0[e] = (INIT && k == 0) ? (float)d.q[k][e] * w[k] : fmaf((float)d.q[k][e], w[k], a0[e]);
-            a1[e] = (INIT && k == 0) ? (float)d.q[k][4 + e] * w[k] : fmaf((float)d.q[k][4 + e], w[k], a1[e]);
-        }
-        acc[2].x = (INIT && k == 0) ? (float)d.u[k].x * w[k] : fmaf((float)d.u[k].x, w[k], acc[2].x);
-        acc[2].y = (INIT && k == 0) ? (float)d.u[k].y * w[k] : fmaf((float)d.u[k].y, w[k], acc[2].y);
-    }
-}
 
 // Two x-adjacent floats in one 8-byte load (4-byte aligned; gfx950 global loads need dword alignment only).
 typedef float F2v __attribute__((ext_vector_type(2)));
@@ -698,6 +677,7 @@ typedef F2v F2u __attribute__((aligned(4)));  // a vector type, so it can be loa
 struct RgbTaps { unsigned o0, o1; float w00, w10, w01, w11; };
 struct RgbData { F2u a[3], b[3]; };
 __device__ __forceinline__ RgbTaps rgb_taps(int Ho, int Wo, float px, float py) {
+#pragma clang fp contract(off)
     // px, py are pixel coordinates: grid g = 2*px/Wo - 1 -> ((g+1)*Wo - 1)/2 = px - 0.5
     float x = fminf(fmaxf(px - 0.5f, 0.f), (float)(Wo - 1)), y = fminf(fmaxf(py - 0.5f, 0.f), (float)(Ho - 1));
     float yf = floorf(y);
@@ -731,7 +711,8 @@ __device__ __forceinline__ void wave_prio(bool last_tile, bool gather) {
         else            { if (gather) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     }
 }
-#ifndef GDB_XP_PRIO_SOLO
+#if !defined(GDB_DIAG) || !defined(GDB_XP_PRIO_SOLO)   // (an experiment of the diagnostic build: profiles/r04/ab_wave_priority.txt)
+#undef GDB_XP_PRIO_SOLO
 #define GDB_XP_PRIO_SOLO 0
 #endif
 
@@ -834,9 +815,24 @@ __device__ __forceinline__ void view_dir_code(const float ctr[3], const float td
 // Gather of one (sample slot, view) for this lane: two sub-ray colours, this half's feature
 // chunks at the footprint's mip level, the view-direction code.  bundle_sampler.py:327-369
 // P16: the feature taps come from the half-precision pyramid (GDB_PREC_F16).
-template <bool P16>
+// a_i <- half 0's a_i in both halves, b_i <- half 1's a_i in both halves (b_i = a_i on entry): v_permlane32_swap_b32 a, b trades the upper
+// 32 lanes of a for the lower 32 lanes of b.  Same caveats as swap32_3: every operand is the result of a plain VALU instruction, the
+// s_nop pairs are the hazard padding; scalars in and out of the asm statement (see xchg9).
+__device__ __forceinline__ void xchg8(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, float& a4, float& a5, float& a6, float& a7,
+                                      unsigned& b0, unsigned& b1, unsigned& b2, unsigned& b3, float& b4, float& b5, float& b6, float& b7) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+                 "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                 "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                   "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+}
+// GDB_PREC_F32 / F32X: the feature taps come from the fp32 pyramid, the colours from the planar fp32 source images.
+// The bilinear taps of the two mip levels are computed ONCE per sample (round 5): lane half 0 forms level l0's byte offsets and weights,
+// half 1 level l1's (the same instructions on per-lane level data), and v_permlane32_swap hands each half the other's - 16 + 2
+// instructions against make_taps' ~86 a second time.  On the fp32 datapath a vector instruction is matrix time.
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float td[3], float4 feat[3], float dir[4], float rgb[2][3], int skip) {
+#pragma clang fp contract(off)   // (every fused multiply-add below is written fmaf: see tex_coord_f)
     float sc[SRC_STRIDE];  // (bi, v) are wave-uniform: scalar loads (of the entries used below), the block lives in SGPRs
     {
         const kfloat* scg = kptr(src_cam(f, bi, v));
@@ -853,10 +849,10 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     for (int r = 0; r < 3; ++r)
         cc[r] = fmaf(sc[S_E + 4 * r], ctr[0], fmaf(sc[S_E + 4 * r + 1], ctr[1], fmaf(sc[S_E + 4 * r + 2], ctr[2], sc[S_E + 4 * r + 3])));
     // footprint -> mip level   :343-348
-    float d2 = cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2];
+    float d2 = fmaf(cc[2], cc[2], fmaf(cc[1], cc[1], cc[0] * cc[0]));
     float icz = frcp(cc[2]), ib = frcp(ball);
     float sec2 = d2 * icz * icz;
-    float aa = fsqrt(fmaxf(d2 * ib * ib - 1.f, 1e-12f)), cq = fsqrt(fmaxf(sec2 - 1.f, 1e-12f));
+    float aa = fsqrt(fmaxf(fmaf(d2 * ib, ib, -1.f), 1e-12f)), cq = fsqrt(fmaxf(sec2 - 1.f, 1e-12f));
     float level = __builtin_amdgcn_logf(sec2 * frcp(aa + cq) * sc[S_IPIXR]);  // v_log_f32 = log2
     float ci[3];
 #pragma unroll
@@ -866,22 +862,24 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     // linear-mipmap-linear fetch as one 8-tap weighted sum   :355-359
     int l0, l1; float frac;
     mip_select(level, f.levels, l0, l1, frac);
-    // (the half-precision copy has the same element offsets: 2 bytes per element instead of 4)
-    const void* pyr = P16 ? (const void*)((const char*)f.pyr16 + ((size_t)bi * f.V + v) * f.pyrStride * 2)
-                          : (const void*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
+    const void* pyr = (const void*)(f.pyr + ((size_t)bi * f.V + v) * f.pyrStride);
     // level offsets as register values: left as f.lvlOff[...] selects, the compiler selects the *address* and
     // issues a per-lane load from kernarg memory (a full vector-memory round trip for a constant)
     unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
     asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
-    const unsigned o0 = l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3));
-    typedef typename std::conditional<P16, Taps16, Taps>::type TapsT;
-    typedef typename std::conditional<P16, TapData16, TapData>::type TapDataT;
-    auto mk = [&](int l, unsigned off, float lw) {
-        if constexpr (P16) return make_taps16(tu, tvv, f.W >> l, f.H >> l, off << 1, lw);
-        else return make_taps(tu, tvv, f.W >> l, f.H >> l, off << 2, lw);
-    };
-    auto ld = [&](const TapsT& t, TapDataT& d) { if constexpr (P16) taps_load16(pyr, t, h, d); else taps_load(pyr, t, h, d); };
-    const TapsT t0 = mk(l0, o0, 1.f - frac);
+    // this half's level -> byte offsets (level offset included) and weights; then each half gets the other's
+    Taps t0, t1;
+    {
+        const int lm = h ? l1 : l0;
+        const unsigned om = lm == 0 ? 0u : (lm == 1 ? lo1 : (lm == 2 ? lo2 : lo3));
+        const Taps m = make_taps(tu, tvv, f.W >> lm, f.H >> lm, om << 2, h ? frac : 1.f - frac);
+        unsigned a0 = m.o00, a1 = m.o10, a2 = m.o01, a3 = m.o11, b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+        float a4 = m.w00, a5 = m.w10, a6 = m.w01, a7 = m.w11, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
+        xchg8(a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7);   // a: half 0's values (level l0), b: half 1's (level l1)
+        t0.o00 = a0; t0.o10 = a1; t0.o01 = a2; t0.o11 = a3; t0.w00 = a4; t0.w10 = a5; t0.w01 = a6; t0.w11 = a7;
+        t1.o00 = b0; t1.o10 = b1; t1.o01 = b2; t1.o11 = b3; t1.w00 = b4; t1.w10 = b5; t1.w01 = b6; t1.w11 = b7;
+        t0.planeB = 16u * __umul24(f.W >> l0, f.H >> l0); t1.planeB = 16u * __umul24(f.W >> l1, f.H >> l1);
+    }
     const bool two = frac > 0.f && do_tex;
     RgbTaps rt[2];
 #pragma unroll
@@ -894,23 +892,176 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         rt[e] = rgb_taps(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
     }
     // ---- issue: level 0 and both sub-rays' colours in flight together -------------------------------
-    TapDataT d0, d1;
+    TapData d0, d1;
     RgbData rd[2];
-    if (do_tex) ld(t0, d0);
+    if (do_tex) taps_load(pyr, t0, h, d0);
     const unsigned plane = (unsigned)(f.Ho * f.Wo);
     if (do_rgb) { rgb_load(img, plane, rt[0], rd[0]); rgb_load(img, plane, rt[1], rd[1]); }
     // ---- consume level 0, issue level 1, consume the colours under its latency, consume level 1 -------
-    if (do_tex) { if constexpr (P16) taps_acc16<true>(t0, d0, feat); else taps_acc<true>(t0, d0, feat); }
+    if (do_tex) taps_acc<true>(t0, d0, feat);
     else feat[0] = feat[1] = feat[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    TapsT t1 = t0;
-    if (two) {
-        const unsigned o1 = l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3);
-        t1 = mk(l1, o1, frac);
-        ld(t1, d1);
-    }
+    if (two) taps_load(pyr, t1, h, d1);
     if (do_rgb) { rgb_combine(rt[0], rd[0], rgb[0]); rgb_combine(rt[1], rd[1], rgb[1]); }
     else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
-    if (two) { if constexpr (P16) taps_acc16<false>(t1, d1, feat); else taps_acc<false>(t1, d1, feat); }
+    if (two) taps_acc<false>(t1, d1, feat);
+    view_dir_code(ctr, td, sc + S_C, dir);
+}
+
+// ---- the GDB_PREC_F16 gather (round 5) -------------------------------------------------------------------------------------------------
+// Same arithmetic as gather_view<true> on the same half-precision pyramid, re-cut for what bounds the f16 kernels (profiles/r05/
+// pmc_c5_f16_baseline.txt: texture addresser 86 % busy, vector ALU 84 %): fewer load instructions and fewer address instructions.
+//  * colours from the half-precision RGBA copy of the source images (gdb_internal.h IMG16_*): an x pair of a tap row is ONE 16-byte
+//    load, 4 per view and lane instead of 12 eight-byte ones;
+//  * plane 2 of the pyramid (channels 16..19) as x pairs: one 16-byte load per tap row, 2 per level instead of 4 four-byte ones;
+//  * the bilinear taps of the two mip levels are computed ONCE per sample: lane half 0 forms level l0's texel indices and weights,
+//    half 1 level l1's, and v_permlane32_swap hands each half the other's (18 instructions against make_taps16's ~86 a second time).
+// 28 -> 16 load instructions and ~60 fewer vector instructions per (sample, view).
+struct Taps16s { unsigned p00, p10, p01, p11; int edge; float w00, w10, w01, w11; };   // main-plane texel indices; x0 is the row's last texel
+__device__ __forceinline__ Taps16s make_taps16s(float u, float v, int W, int H, float lw) {
+#pragma clang fp contract(off)
+    int x0, x1, y0, y1; float fx, fy;
+    tex_coord_f(u, W, x0, x1, fx);
+    tex_coord_f(v, H, y0, y1, fy);
+    Taps16s t;
+    const unsigned r0 = __umul24(y0, W), r1 = __umul24(y1, W);
+    t.p00 = r0 + x0; t.p10 = r0 + x1; t.p01 = r1 + x0; t.p11 = r1 + x1;
+    t.edge = (x0 > W - 2 && W >= 2) ? 1 : 0;   // the pair (x0, x0 + 1) would leave the row: taken one texel to the left, weight on its second element
+    const float ex = (1.f - fx) * lw, wx = fx * lw;
+    t.w00 = ex * (1.f - fy); t.w10 = wx * (1.f - fy); t.w01 = ex * fy; t.w11 = wx * fy;
+    return t;
+}
+// a <- half 0's a in both halves, b <- half 1's a in both halves (v_permlane32_swap_b32 a, b: the upper 32 lanes of a trade places with the
+// lower 32 lanes of b; same caveats as swap32_3: operands are results of plain VALU instructions, the s_nop pairs are the hazard padding)
+// (scalars in and out of the asm statement, never members of a struct by reference: a struct whose members are asm operands was
+// parked in PRIVATE MEMORY by hipcc in one instantiation - the kind of round trip build.py refuses in these kernels)
+__device__ __forceinline__ void xchg9(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, int& a4, float& a5, float& a6, float& a7, float& a8,
+                                      unsigned& b0, unsigned& b1, unsigned& b2, unsigned& b3, int& b4, float& b5, float& b6, float& b7, float& b8) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %9\n\tv_permlane32_swap_b32 %1, %10\n\tv_permlane32_swap_b32 %2, %11\n\t"
+                 "v_permlane32_swap_b32 %3, %12\n\tv_permlane32_swap_b32 %4, %13\n\tv_permlane32_swap_b32 %5, %14\n\t"
+                 "v_permlane32_swap_b32 %6, %15\n\tv_permlane32_swap_b32 %7, %16\n\tv_permlane32_swap_b32 %8, %17\n\ts_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
+                   "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(b8));
+}
+struct TapData16s { half8v q[4]; half8v u[2]; };   // four main-plane texels; plane-2 x pairs of the two tap rows
+__device__ __forceinline__ void taps_load16s(const void* __restrict__ pyr16, const Taps16s& t, unsigned lvlB, unsigned hw, int h, TapData16s& d) {
+    const unsigned b0 = lvlB + (h ? 16u * hw : 0u), b2 = lvlB + PYR16_PLANE2(hw);
+    d.q[0] = ldu<half8v>(pyr16, b0 + 16u * t.p00); d.q[1] = ldu<half8v>(pyr16, b0 + 16u * t.p10);
+    d.q[2] = ldu<half8v>(pyr16, b0 + 16u * t.p01); d.q[3] = ldu<half8v>(pyr16, b0 + 16u * t.p11);
+    typedef half8v half8u __attribute__((aligned(8)));   // (8-byte aligned 16-byte loads: dword alignment suffices on gfx950)
+    d.u[0] = ldu<half8u>(pyr16, b2 + 8u * (t.p00 - (unsigned)t.edge)); d.u[1] = ldu<half8u>(pyr16, b2 + 8u * (t.p01 - (unsigned)t.edge));
+}
+template <bool INIT>
+__device__ __forceinline__ void taps_acc16s(const Taps16s& t, const TapData16s& d, int h, float4 acc[3]) {
+    const float w[4] = {t.w00, t.w10, t.w01, t.w11};
+    float* a0 = (float*)&acc[0]; float* a1 = (float*)&acc[1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0[e] = (INIT && k == 0) ? (float)d.q[k][e] * w[k] : fmaf((float)d.q[k][e], w[k], a0[e]);
+            a1[e] = (INIT && k == 0) ? (float)d.q[k][4 + e] * w[k] : fmaf((float)d.q[k][4 + e], w[k], a1[e]);
+        }
+    }
+    // plane 2: pair element 0 = texel x0 - edge, element 1 = the next; at the row's end the tap x0 IS element 1 (and x1 = x0 carries no weight)
+    const float pa = t.edge ? 0.f : t.w00, pb = t.edge ? t.w00 + t.w10 : t.w10, pc = t.edge ? 0.f : t.w01, pd = t.edge ? t.w01 + t.w11 : t.w11;
+    // this half's two channels (16 + 2h, 17 + 2h) of both texels of a pair = dword h (first texel) and dword 2 + h (second) of the 16 bytes
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v ua = __builtin_bit_cast(u4v, d.u[0]), ub = __builtin_bit_cast(u4v, d.u[1]);
+    const hpair a0p = unpack_h2(h ? ua.y : ua.x), a1p = unpack_h2(h ? ua.w : ua.z), b0p = unpack_h2(h ? ub.y : ub.x), b1p = unpack_h2(h ? ub.w : ub.z);
+    const _Float16 r0x0a = a0p.x, r0x0b = a0p.y, r0x1a = a1p.x, r0x1b = a1p.y, r1x0a = b0p.x, r1x0b = b0p.y, r1x1a = b1p.x, r1x1b = b1p.y;
+    // (same products in the same order as taps_acc16: tap (x0,y0), (x1,y0), (x0,y1), (x1,y1); a zero-weight product adds an exact zero)
+    float sx = INIT ? (float)r0x0a * pa : fmaf((float)r0x0a, pa, acc[2].x), sy = INIT ? (float)r0x0b * pa : fmaf((float)r0x0b, pa, acc[2].y);
+    sx = fmaf((float)r0x1a, pb, sx); sy = fmaf((float)r0x1b, pb, sy);
+    sx = fmaf((float)r1x0a, pc, sx); sy = fmaf((float)r1x0b, pc, sy);
+    acc[2].x = fmaf((float)r1x1a, pd, sx); acc[2].y = fmaf((float)r1x1b, pd, sy);
+}
+// colour taps from the half-precision RGBA copy: byte offsets of the two tap rows' x pairs inside one (batch, view) image
+__device__ __forceinline__ RgbTaps rgb_taps16(int Ho, int Wo, float px, float py) {
+    RgbTaps t = rgb_taps(Ho, Wo, px, py);
+    t.o0 *= 2u; t.o1 *= 2u;   // 8 bytes per pixel instead of 4
+    return t;
+}
+struct RgbData16 { half8v a, b; };
+__device__ __forceinline__ void rgb_load16(const void* __restrict__ img16, const RgbTaps& t, RgbData16& d) {
+    typedef half8v half8u __attribute__((aligned(8)));
+    d.a = ldu<half8u>(img16, t.o0); d.b = ldu<half8u>(img16, t.o1);
+}
+__device__ __forceinline__ void rgb_combine16(const RgbTaps& t, const RgbData16& d, float rgb[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = fmaf((float)d.b[4 + c], t.w11, fmaf((float)d.b[c], t.w01, fmaf((float)d.a[4 + c], t.w10, (float)d.a[c] * t.w00)));
+}
+__device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
+                                              float ball, const float td[3], float4 feat[3], float dir[4], float rgb[2][3], int skip) {
+#pragma clang fp contract(off)   // (every fused multiply-add below is written fmaf: see tex_coord_f)
+    float sc[SRC_STRIDE];
+    {
+        const kfloat* scg = kptr(src_cam(f, bi, v));
+        asm volatile("" : "+s"(scg));
+#pragma unroll
+        for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
+    }
+    const bool do_rgb = !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
+    // ---- footprint -> mip level, texture coordinates (as gather_view)   bundle_sampler.py:340-353 -----------------------------------
+    float cc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        cc[r] = fmaf(sc[S_E + 4 * r], ctr[0], fmaf(sc[S_E + 4 * r + 1], ctr[1], fmaf(sc[S_E + 4 * r + 2], ctr[2], sc[S_E + 4 * r + 3])));
+    float d2 = fmaf(cc[2], cc[2], fmaf(cc[1], cc[1], cc[0] * cc[0]));
+    float icz = frcp(cc[2]), ib = frcp(ball);
+    float sec2 = d2 * icz * icz;
+    float aa = fsqrt(fmaxf(fmaf(d2 * ib, ib, -1.f), 1e-12f)), cq = fsqrt(fmaxf(sec2 - 1.f, 1e-12f));
+    float level = __builtin_amdgcn_logf(sec2 * frcp(aa + cq) * sc[S_IPIXR]);
+    float ci[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ci[r] = fmaf(sc[S_KS + 3 * r], cc[0], fmaf(sc[S_KS + 3 * r + 1], cc[1], sc[S_KS + 3 * r + 2] * cc[2]));
+    float izc = frcp(fmaxf(ci[2], 1e-6f));
+    float tu = ci[0] * izc * f.invW, tvv = ci[1] * izc * f.invH;
+    int l0, l1; float frac;
+    mip_select(level, f.levels, l0, l1, frac);
+    // the pyramid block and the image block of this (batch, view): wave-uniform bases, 32-bit offsets below
+    const size_t bvi = (size_t)bi * f.V + v;
+    const void* pyr = (const void*)((const char*)f.pyr16 + bvi * f.pyrStride * 2);
+    const void* img = (const void*)((const char*)f.pyr16 + IMG16_REL(f.pyrStride, (size_t)f.B * f.V) + bvi * ((size_t)f.Ho * f.Wo * 8));
+    unsigned lo1 = f.lvlOff[1], lo2 = f.lvlOff[2], lo3 = f.lvlOff[3];
+    asm volatile("" : "+s"(lo1), "+s"(lo2), "+s"(lo3));
+    // ---- this half's level: texel indices and weights; then each half gets the other's ----------------------------------------
+    const int lm = h ? l1 : l0;
+    Taps16s t0, t1;
+    {
+        const Taps16s m = make_taps16s(tu, tvv, f.W >> lm, f.H >> lm, h ? frac : 1.f - frac);
+        unsigned a0 = m.p00, a1 = m.p10, a2 = m.p01, a3 = m.p11, b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+        int a4 = m.edge, b4 = a4;
+        float a5 = m.w00, a6 = m.w10, a7 = m.w01, a8 = m.w11, b5 = a5, b6 = a6, b7 = a7, b8 = a8;
+        xchg9(a0, a1, a2, a3, a4, a5, a6, a7, a8, b0, b1, b2, b3, b4, b5, b6, b7, b8);   // a: half 0's values (level l0), b: half 1's (level l1)
+        t0.p00 = a0; t0.p10 = a1; t0.p01 = a2; t0.p11 = a3; t0.edge = a4; t0.w00 = a5; t0.w10 = a6; t0.w01 = a7; t0.w11 = a8;
+        t1.p00 = b0; t1.p10 = b1; t1.p01 = b2; t1.p11 = b3; t1.edge = b4; t1.w00 = b5; t1.w10 = b6; t1.w01 = b7; t1.w11 = b8;
+    }
+    const unsigned o0 = 2u * (l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3))), hw0 = __umul24(f.W >> l0, f.H >> l0);
+    const bool two = frac > 0.f && do_tex;
+    RgbTaps rt[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
+        float im[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            im[r] = fmaf(sc[S_P + 4 * r], xyz[e][0], fmaf(sc[S_P + 4 * r + 1], xyz[e][1], fmaf(sc[S_P + 4 * r + 2], xyz[e][2], sc[S_P + 4 * r + 3])));
+        float iz = frcp(fmaxf(im[2], 1e-6f));
+        rt[e] = rgb_taps16(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
+    }
+    // ---- issue: level 0 and both sub-rays' colours in flight together (6 + 4 loads) ---------------------------------------------
+    TapData16s d0, d1;
+    RgbData16 rd[2];
+    if (do_tex) taps_load16s(pyr, t0, o0, hw0, h, d0);
+    if (do_rgb) { rgb_load16(img, rt[0], rd[0]); rgb_load16(img, rt[1], rd[1]); }
+    if (do_tex) taps_acc16s<true>(t0, d0, h, feat);
+    else feat[0] = feat[1] = feat[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (two) {
+        const unsigned o1 = 2u * (l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3)), hw1 = __umul24(f.W >> l1, f.H >> l1);
+        taps_load16s(pyr, t1, o1, hw1, h, d1);
+    }
+    if (do_rgb) { rgb_combine16(rt[0], rd[0], rgb[0]); rgb_combine16(rt[1], rd[1], rgb[1]); }
+    else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
+    if (two) taps_acc16s<false>(t1, d1, h, feat);
     view_dir_code(ctr, td, sc + S_C, dir);
 }
 
@@ -921,6 +1072,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
 template <int PREC>
 __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, const float* __restrict__ tc, const Bundle<4>& q, int k, int bi,
                                               int j, int h, int skip, bool act, float& z, float vox[4]) {
+#pragma clang fp contract(off)   // (the voxel taps' coordinates and weights: see tex_coord_f; the tap sums below are written fmaf)
     const int V = f.V;
     float dn, ball, xyz[4][3], ctr[3];
     bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
@@ -978,7 +1130,10 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
         // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
         float dir[4], rgb[2][3];
-        if (act) gather_view<PREC == GDB_PREC_F16>(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        if (act) {
+            if constexpr (PREC == GDB_PREC_F16) gather_view16(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+            else gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        }
         else {
             const float u = __builtin_nondeterministic_value(0.f);
             feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
@@ -1257,9 +1412,9 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
 // section layout above) — no conversion, no LDS, no lane movement; ReLU is one integer max per register.
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ f32x4 load_quad(const float* __restrict__ m32, int q, int lane) {
-#if defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // timing experiment (wrong results): no weight loads at all
+#if defined(GDB_DIAG) && defined(GDB_XP_NOW) && GDB_XP_NOW == 1   // diagnostic build only - timing experiment (wrong results): no weight loads at all
     f32x4 r; asm volatile("" : "=v"(r)); return r;
-#elif defined(GDB_XP_NOW) && GDB_XP_NOW == 2  // timing experiment (wrong results): every weight load hits the same 1 KiB (L1-resident)
+#elif defined(GDB_DIAG) && defined(GDB_XP_NOW) && GDB_XP_NOW == 2  // diagnostic build only - timing experiment (wrong results): every weight load hits the same 1 KiB (L1-resident)
     return ldu_pin<f32x4>(m32 + (size_t)(q & 1) * 256, (unsigned)lane * 16u);
 #else
     return ldu_pin<f32x4>(m32 + (size_t)q * 256, (unsigned)lane * 16u);
@@ -1921,214 +2076,19 @@ __device__ __forceinline__ int dense_fill(const DevFrame& f, int rlo, int rhi, i
     return i;
 }
 
-// PERSIST: the wave walks several tiles (the launch is the resident grid).  false: the grid has one wave per tile of the worst case
-// and a wave renders at most ONE tile - then nothing has to be kept out of the tile loop's way and the kernel arguments are plain
-// loop-free SGPR values again (the persistent form re-reads them through an opaque pointer in every tile: ~15 more scalar loads and
-// their waits per tile, 3 % of a tile at fp32).  The launcher takes the persistent form where the static walk wins (few tiles per
-// wave slot: c2) and this one elsewhere (c3 / c4: the hardware dispatcher balances uneven tiles better than a static stride).
-template <int PREC, int WPS, int NWG, bool PERSIST>
-__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) {
-    // Everything wave-uniform is re-derived inside each tile iteration from an opaque pointer to the kernel-argument segment (as in
-    // k_render_solo): as loop invariants those values would be live across the whole body, which has no register to spare.
-    typedef const FusedArgs __attribute__((address_space(4))) KArgs;
-    KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    // ---- this wave's tiles: t0, t0 + stride, ... < tend, looked up once (dense_fill) ---------------------------------------------
-    // Rows are addressed by their global index (batch item x H + row), so one launch covers the rows [row_lo, row_hi) of ALL batch
-    // items, and nothing but the descriptor register and two counters lives across a tile.
-    unsigned vdesc;
-    int ntile;
-    {
-        const FusedArgs& a = *(const FusedArgs*)ap;
-        const int lane = threadIdx.x & 63, wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-        // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2); XCD x walks the band [x chunk, (x + 1) chunk) of the tiles
-        ntile = __builtin_amdgcn_readfirstlane(dense_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
-                                                          a.tile_stride, vdesc));
-    }
-    if (ntile <= 0) return;
-    int it = 0;
-    do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
-    wave_prio<PERSIST>(it + 1 >= ntile, true);   // (the one-tile form measured 1 % slower with it: c3)
-    KArgs* apk = ap;
-    if constexpr (PERSIST) asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
-    // The arguments as VALUES: the by-value kernel parameter when the wave renders one tile (the compiler fetches it in a few wide
-    // scalar loads at kernel entry), a copy made at the top of every tile of the walk (one burst of scalar loads, through the opaque
-    // pointer so that nothing of it lives across tiles).  Read field by field through the pointer instead, each use paid a scalar
-    // load and its wait where it stood: +2.5 % on a tile (c3 fp32 180.5 -> 176.0 us, c4 211.7 -> 206.9: profiles/r04/ab_kernarg_access.txt).
-    const FusedArgs a_copy = *(const FusedArgs*)apk;
-    const FusedArgs& a = PERSIST ? a_copy : a_;
-    const DevFrame& f = a.f;
-    // ... and so is everything per-lane: nothing derived from the lane index may be hoisted out of the tile loop either
-    const int tid = PERSIST ? opaque((int)threadIdx.x) : (int)threadIdx.x;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
-    float* stage = (float*)smem4 + (size_t)wv * a.wave_floats;
-#ifdef GDB_DEBUG_STAMPS  // one stamp record per (wave slot, tile iteration)
-    unsigned* dbg = a.dbg ? a.dbg + (size_t)it * gridDim.x * (16 * 16 * 2) : nullptr;
-#else
-    unsigned* dbg = nullptr; (void)dbg;
-#endif
-    // ---- dense tile index -> (row, window) -------------------------------------------------------------------------------
-    const unsigned desc = (unsigned)__builtin_amdgcn_readlane((int)vdesc, it);
-    if (desc == 0xFFFFFFFFu) continue;
-    int rowid = (int)(desc >> 16), win = (int)(desc & 0xFFFFu);
-    if (rowid < a.row_lo || rowid >= a.row_hi) continue;
-    const int bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? rowid / f.H : 0), row = rowid - bi * f.H;
-    typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
-    const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
-    if (win >= krec[0]) continue;  // (cannot happen with a plan that belongs to this depth prior)
-    // This window = the row's sample offsets [s0, s0 + n), n <= 32, whole bundles (plan_row).  Everything read from the plan is
-    // clamped to the frame, so that a plan that does not belong to this frame's depth prior renders garbage instead of reading or
-    // writing outside the frame.
-    const int s0 = min(max(krec[1 + win], 0), f.smapStride - 32);
-    const int n = min(max(krec[2 + win] - s0, 0), 32);
-    if (n <= 0) continue;
-    const unsigned m = ldu<unsigned>(f.smap + (size_t)rowid * f.smapStride, 4u * (unsigned)(s0 + j));  // lane j = sample s0 + j of the row
-    float tc[TAR_STRIDE];
-    {
-        const kfloat* tcg = kptr(tar_cam(f, bi));
-        if constexpr (PERSIST) asm volatile("" : "+s"(tcg));
-#pragma unroll
-        for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
-    }
-    STAMP(0);
-    const int mx = (int)(m & 0xFFFFu), k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
-    // the window's bundles: first (lane 0's: a window starts at a bundle's first sample) .. the last lane's, nb <= 32
-    const int first = min(max(__builtin_amdgcn_readfirstlane(mx), 0), f.W - 1);
-    const int nb = min(max(__builtin_amdgcn_readlane(mx, n - 1) - first + 1, 0), min(32, f.W - first));
-    if (nb <= 0) continue;
-    const int bj_g = min(max(mx - first, 0), nb - 1);        // this sample's bundle inside the window (= its output column)
-    const bool act = j < n && m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k_g >= 0 && k_g < mcnt && mcnt <= f.S_max;
-    const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
-    const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
-    float vox[4];
-    {
-        float z_g;
-        Bundle<4> q;
-        load_bundle<4, true, false>(f, tc, bi, row, first + bj_g, q);
-        q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
-        STAMP(1);
-        slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
-    }
-    STAMP(2);
-    wave_prio<PERSIST>(it + 1 >= ntile, false);
-    __builtin_amdgcn_wave_barrier();
-    PHASE_FENCE();
-    float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
-    float sig;
-    {
-        float bacc[16], fhv[4];
-        if (PREC == GDB_PREC_F32) slot_mlp_core_f32(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
-        else slot_mlp_core<PREC == GDB_PREC_F32X>(f, mfg, stage, vox, lane, j, h, b_agg, b_w2, dbg, bacc, fhv, sig);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = bacc[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[16 + i] = fhv[i];
-    }
-    // ---- composite across the lanes of a bundle --------------------------------------------------------------------------
-    // The sample's slot, count and output column are decoded AGAIN from its list entry (one register across gather + MLP instead
-    // of four: the split-f16 build has none to spare).
-    const unsigned m_c = (unsigned)opaque((int)m);
-    const int k = (int)((m_c >> 16) & 0xFFu), cnt = min(max((int)(m_c >> 24), 1), f.S_max);
-    const int bj = min(max((int)(m_c & 0xFFFFu) - first, 0), nb - 1);
-    float z;  // the sample's depth, derived again from the depth prior (two loads the gather has left in L1 / L2) as bundle_sample does
-    {
-        const size_t hw = (size_t)f.H * f.W;
-        const unsigned pz = 4u * (unsigned)(row * f.W + first + bj);
-        float n0 = ldu<float>(f.depth_range + ((size_t)bi * 2) * hw, pz), f0 = ldu<float>(f.depth_range + ((size_t)bi * 2 + 1) * hw, pz);
-        if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
-        z = sample_mid<true>(n0, f0, cnt, min(k, cnt - 1));
-        if (f.inv_depth) z = gdiv<true>(1.f, z);
-    }
-    const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
-    const int S = f.S_max;
-    if (S <= 4) {
-        // An active sample's earlier samples are the lanes just below it in the same half (k <= j), a bundle's later samples the
-        // lanes just above (they end at lane 31 at the latest): whole-wave DPP shifts never carry a value across a bundle's edge
-        // that the predicates below do not mask.
-        float Tr = 1.f, ap_ = al;
-#pragma unroll
-        for (int d = 1; d < 4; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
-            ap_ = wave_shr1(ap_);
-            if (d <= k) Tr *= 1.f - ap_;
-        }
-        const float w = al * Tr;
-#pragma unroll
-        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
-        v[20] = w;
-        v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
-        // Segmented suffix sums as a Horner chain: acc <- v + (the bundle has a next sample ? acc of the next lane : 0); after
-        // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.  The neighbour is masked with a SELECT, not a
-        // multiply by 0: a non-finite sum of the next bundle must stay in its own bundle (as in the other schedules and the reference).
-        // (The select sits on the SOURCE lane - "I continue the bundle of the lane below" - so that the shift folds into the add:
-        // v_cndmask + v_add_f32_dpp, two instructions per value and step; profiles/r04/ab_single_changes_f32.txt has the earlier forms.)
-        const bool is_cont = act && k > 0;   // this lane continues the bundle of the lane below it
-        float acc[22];
-#pragma unroll
-        for (int i = 0; i < 22; ++i) acc[i] = v[i];
-        for (int d = 1; d < S; ++d) {
-#pragma unroll
-            // mask at the SOURCE lane (a continuation lane: active, slot > 0), then one DPP add per value: acc <- v + shl(masked acc)
-            for (int i = 0; i < 22; ++i) { const float mk = is_cont ? acc[i] : 0.f; acc[i] = v[i] + wave_shl1(mk); }
-        }
-#pragma unroll
-        for (int i = 0; i < 22; ++i) v[i] = acc[i];
-    } else {
-        float Tr = 1.f;
-        for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
-            const float ap_ = __shfl_up(al, d, 32);
-            if (d <= k) Tr *= 1.f - ap_;
-        }
-        const float w = al * Tr;
-#pragma unroll
-        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
-        v[20] = w;
-        v[21] = act ? w * (f.inv_depth ? 1.f / z : z) : 0.f;
-        for (int d = 1; d < S; d <<= 1) {  // segmented suffix sums by doubling (ds_bpermute): the bundle's first lane ends with its sums
-            const bool take = act && k + d < cnt;
-#pragma unroll
-            for (int i = 0; i < 22; ++i) {
-                const float tt = __shfl_down(v[i], d, 32);
-                if (take) v[i] += tt;
-            }
-        }
-    }
-    STAMP(7);
-    __builtin_amdgcn_wave_barrier();
-    PHASE_FENCE();
-    float* o = stage;  // the output record: [bundles of the window][ld] (+ depth, opacity behind it in the three-tensor form)
-    const int ld = a.ldo;
-    if (act && k == 0) {
-        const float rden = 1.f / fmaxf(v[20], 1e-6f);
-        out_store_own16(o, ld, bj, h, [&](int i) { return v[i] * rden; });
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[bj * ld + NBLEND + 4 * h + i] = v[16 + i] * rden;
-        if (h == 0) {
-            const float d = v[21] * rden;
-            *out_depth_slot(o, ld, bj) = f.inv_depth ? 1.f / d : d;  // network.py:88-89
-            *out_opac_slot(o, ld, bj) = v[20] * rden;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    PHASE_FENCE();
-    const size_t b0 = ((size_t)bi * f.H + row) * f.W + (size_t)first;
-    out_copy(a, o, b0, nb, lane);
-    STAMP(8); STAMP(9);
-    __builtin_amdgcn_wave_barrier();  // the next tile's gather overwrites the area the stores above read
-    PHASE_FENCE();
-    } while (PERSIST && ++it < ntile);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Flat schedule (GDB_SCHED_FLAT): the rows' compacted sample lists read as ONE list - literally the reference's flat sample list
 // (bundle_sampler.py:182-189) - cut into windows of exactly 32 consecutive samples: every lane of every wave but the list's last
 // carries a sample (the window plan of the dense schedule keeps bundles whole: 92-96 % of the lanes).  c2: 6,112 tiles instead of
 // 6,631 - which also is at most TWO tiles per resident wave slot (3,072), where 6,631 left a third, nearly empty round that a lone
 // wave per SIMD crawled through.
-// The price: a window may begin or end INSIDE a bundle.  Such a bundle is composited by neither wave: both leave the per-sample
-// records of their part (20 pre-weight values per lane half, alpha, the depth term) in the workspace, keyed by the window
-// boundary, and k_flat_fix - a small launch behind the render - composites it with exactly the arithmetic of the in-wave composite
-// (same products, same order of sums), so that a bundle's result does not depend on where the windows fall: row strips of the
-// frame stay bit-identical to the full render.
+// The price: a window may begin or end INSIDE a bundle.  Such a bundle is composited by neither wave's in-register composite:
+// both leave the per-sample records of their part (20 pre-weight values per lane half, alpha, the depth term) in the workspace,
+// keyed by the window boundary, and whichever of the two waves ARRIVES LAST at the boundary's counter composites the bundle from
+// those records (flat_fix_boundary) with exactly the arithmetic of the in-wave composite (same products, same order of sums), so
+// that a bundle's result depends neither on where the windows fall nor on which wave arrived last: row strips of the frame stay
+// bit-identical to the full render and to GDB_SCHED_DENSE.  (Until round 5 a second launch, k_flat_fix, did that: 5 us of launch
+// ramp and two dependent memory round trips behind every render.)
 // A window may also span bundle-map rows (the row of a lane is per-lane; a row holds >= W samples, so two rows in all but tiny maps).
 // Tiles are looked up once per wave like the dense schedule's: descriptor = first row << 16 | sample offset inside that row.
 __device__ __forceinline__ int4 flat_counts(const DevFrame& f, int rlo, int rhi, int c0, int lane, int& s4) {
@@ -2154,8 +2114,8 @@ __device__ __forceinline__ int flat_total(const DevFrame& f, int rlo, int rhi, i
     }
     return T;
 }
-// This wave's tiles (slot `slot` of XCD `xcd`, as dense_fill) -> descriptors, one per lane; T = tiles of the launch (out).
-__device__ __forceinline__ int flat_fill(const DevFrame& f, int rlo, int rhi, int lane, int xcd, int slot, int stride, unsigned& vdesc, int& t0_out, int& T_out) {
+// This wave's tiles (slot `slot` of XCD `xcd`, as dense_fill) -> descriptors, one per lane; t0 = its first tile's index in the launch.
+__device__ __forceinline__ int flat_fill(const DevFrame& f, int rlo, int rhi, int lane, int xcd, int slot, int stride, unsigned& vdesc, int& t0_out) {
     const int q0 = rlo >> 2, nq = ((rhi + 3) >> 2) - q0;
     int s4;
     int4 n = flat_counts(f, rlo, rhi, 0, lane, s4);
@@ -2163,7 +2123,7 @@ __device__ __forceinline__ int flat_fill(const DevFrame& f, int rlo, int rhi, in
     const int NS = nq <= 64 ? __builtin_amdgcn_readlane(incl, 63) : __builtin_amdgcn_readfirstlane(flat_total(f, rlo, rhi, lane));
     const int T = (NS + 31) >> 5;
     const int chunk = (T + 7) >> 3, t0 = xcd * chunk + slot, tend = min(T, (xcd + 1) * chunk);
-    t0_out = t0; T_out = T;
+    t0_out = t0;
     int run = 0, i = 0;
     vdesc = 0xFFFFFFFFu;
     for (int c0 = 0; c0 < nq && i < 64; c0 += 64) {
@@ -2190,39 +2150,147 @@ __device__ __forceinline__ int flat_fill(const DevFrame& f, int rlo, int rhi, in
 __device__ __forceinline__ float* flat_rec(const DevFrame& f, int b, int k, int h) {
     return f.side + ((size_t)((size_t)b * f.S_max + k) * 2 + h) * FLAT_REC;
 }
+// ---- the hand-off of a straddling bundle between its two waves (MI355X guide, "Workgroup dispatch ... inter-workgroup visibility") -----------
+// Producer side, every lane that owns a sample of a straddling bundle: its 24-float record as six WRITE-THROUGH 16-byte stores (sc1: the
+// bytes leave this XCD's L2, nothing to write back later), then the wave drains its stores (s_waitcnt vmcnt(0)) and ONE lane per boundary
+// adds 1 to the boundary's counter (agent-scope returning atomic).  The wave whose add returns 1 is the last of the two: one agent-scope
+// acquire (buffer_inv sc1), then it loads both parts' records with sc1 loads and composites the bundle.  Nobody spins, so no schedule of
+// the two waves can deadlock; the counter is returned to 0 by the last arriver (k_prepare / k_plan zero it once per frame).
+typedef float F4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1_16(float* p, float a, float b, float c, float d) {
+    const F4s v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float load_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int load_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int PREC, int WPS, int NWG, bool PERSIST>
-__global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
+// The bundle that straddles window boundary b, from the per-sample records both waves left: the whole wave, lane (h, i) = lane half x
+// value index (0..19 the weighted values, 20 the weight, 21 weight x depth term), EXACTLY the in-wave composite's arithmetic:
+// transmittance as the product over the earlier samples nearest first, weights alpha x T, the sums right-nested (S_max <= 4: the Horner
+// chain) or by doubling (S_max > 4: the ds_bpermute steps).  NS = slots unrolled (registers, all records requested up front: one memory
+// round trip behind the header's): 4 for S_max <= 4, 16 else.
+template <int NS>
+__device__ __forceinline__ void flat_fix_boundary(const FusedArgs& a, const DevFrame& f, int b, int lane) {
+#pragma clang fp contract(off)
+    const int h = lane >> 5, i = lane & 31, S = f.S_max;
+    const float* r0 = flat_rec(f, b, 0, h);
+    const int gb = load_sc1((const int*)r0 + 22), cnt = load_sc1((const int*)r0 + 23);   // the header rides in slot 0's record (written by the tail side)
+    float val[NS], alv[NS], ztv[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {   // every slot the config can have, unconditionally (slots past the count are unused)
+        const float* r = r0 + (size_t)min(k, S - 1) * 2 * FLAT_REC;
+        alv[k] = load_sc1(r + 20); ztv[k] = load_sc1(r + 21); val[k] = load_sc1(r + (i < 20 ? i : 0));
+    }
+    if (gb < 0 || cnt < 2 || cnt > S || cnt > NS || gb >= f.H * f.W) return;   // (cannot happen with records of this launch)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        float Tr = 1.f;
+#pragma unroll
+        for (int d = 1; d <= k; ++d) if (S > 4 ? d < S : d < 4) Tr *= 1.f - alv[k - d];
+        const float w = alv[k] * Tr;
+        val[k] = i < 20 ? w * val[k] : (i == 20 ? w : w * ztv[k]);
+    }
+    float acc;
+    if (S <= 4) {
+        acc = 0.f;
+        bool started = false;
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k)
+            if (k < cnt) { acc = started ? val[k] + acc : val[k]; started = true; }
+    } else {
+#pragma unroll
+        for (int d = 1; d < NS; d <<= 1)
+            if (d < S) {
+#pragma unroll
+                for (int k = 0; k + d < NS; ++k) if (k + d < cnt) val[k] = val[k] + val[k + d];   // ascending k reads the not yet updated k + d
+            }
+        acc = val[0];
+    }
+    const float wsum = __shfl(acc, (h << 5) | 20), rden = 1.f / fmaxf(wsum, 1e-6f);
+    const size_t row = (size_t)(f.B > 1 ? a.row_lo / f.H : 0) * f.H * f.W + (size_t)gb;
+    int ch = -1;
+    if (i < 16) ch = own_chan(h, i);
+    else if (i < 20) ch = NBLEND + 4 * h + (i - 16);
+    if (ch >= 0) a.bf[row * a.ldo + ch] = acc * rden;
+    if (h == 0 && i == 20) { if (a.ldo == NOUT) a.opac[row] = acc * rden; else a.bf[row * a.ldo + NOUT + 1] = acc * rden; }
+    if (h == 0 && i == 21) {
+        const float d = acc * rden, dd = f.inv_depth ? 1.f / d : d;
+        if (a.ldo == NOUT) a.depth[row] = dd; else a.bf[row * a.ldo + NOUT] = dd;
+    }
+}
+
+// The wave's arrival at its window's boundaries, settled: ticket 1 = it was the second of the boundary's two waves - the other part's
+// records are in memory (their wave drained its write-through stores before its add) and the loads of flat_fix_boundary go past this
+// CU's L1 (sc1); it composites the bundle and returns the counter to zero for the next render.  pend: bit 0 = arrived at boundary b
+// (lane 0 holds that ticket), bit 1 = at boundary b + 1 (lane 1).  GDB_FLAT_ACQUIRE adds the agent-scope acquire of the guide's general
+// recipe (buffer_inv sc1: every wave of the CU then refills its L1); measured beside the default: DESIGN.md.
+__device__ __forceinline__ void flat_settle(const FusedArgs& a, const DevFrame& f, int ticket, int pend, int b, int lane) {
+    const bool last_h = (pend & 1) && __builtin_amdgcn_readlane(ticket, 0) == 1, last_t = (pend & 2) && __builtin_amdgcn_readlane(ticket, 1) == 1;
+    if (!(last_h | last_t)) return;
+#ifdef GDB_FLAT_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if ((lane == 0 && last_h) || (lane == 1 && last_t)) __hip_atomic_store(f.side_hdr + b + (lane & 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.S_max <= 4) {
+        if (last_h) flat_fix_boundary<4>(a, f, b, lane);
+        if (last_t) flat_fix_boundary<4>(a, f, b + 1, lane);
+    } else {
+        if (last_h) flat_fix_boundary<GDB_MAX_SAMPLES>(a, f, b, lane);
+        if (last_t) flat_fix_boundary<GDB_MAX_SAMPLES>(a, f, b + 1, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ONE body for both list schedules (FLAT = false: the dense schedule's windows of whole bundles; true: windows of exactly 32
+// consecutive samples).  k_render_dense / k_render_flat below are its two kernels.
+// PERSIST: the wave walks several tiles (the launch is the resident grid).  false: the grid has one wave per tile of the worst case
+// and a wave renders at most ONE tile - then nothing has to be kept out of the tile loop's way and the kernel arguments are plain
+// loop-free SGPR values again.  GDB_SCHED_AUTO always walks (profiles/r04/ab_walk_vs_one_tile.txt); the one-tile form is what the
+// split-f16 flat build at three waves per SIMD takes (no register left for the walk's loop state) and a diagnostic switch.
+template <int PREC, int NWG, bool PERSIST, bool FLAT>
+__device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
+    // Everything wave-uniform is re-derived inside each tile iteration from an opaque pointer to the kernel-argument segment (as in
+    // k_render_solo): as loop invariants those values would be live across the whole body, which has no register to spare.
     typedef const FusedArgs __attribute__((address_space(4))) KArgs;
     KArgs* const ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    // ---- this wave's tiles: t0, t0 + stride, ... < tend, looked up once (dense_fill / flat_fill) ---------------------------------
+    // Rows are addressed by their global index (batch item x H + row), so one launch covers the rows [row_lo, row_hi) of ALL batch
+    // items (dense; the flat schedule launches per batch item), and nothing but the descriptor register and two counters lives across a tile.
     unsigned vdesc;
-    int ntile, t0;
+    int ntile, t0 = 0;
     {
         const FusedArgs& a = *(const FusedArgs*)ap;
         const int lane = threadIdx.x & 63, wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-        int T;
-        ntile = __builtin_amdgcn_readfirstlane(flat_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
-                                                         a.tile_stride, vdesc, t0, T));
-        t0 = __builtin_amdgcn_readfirstlane(t0);
-        // k_flat_fix is launched for the worst-case number of boundaries: those behind the list's end (never written by a tile) are
-        // marked empty here, a few per wave.  (The "header" of a boundary - which bundle straddles it, how many samples it has - rides
-        // in the two padding floats of the slot-0 records: the fix-up fetches everything of a boundary in ONE memory round trip.)
-        {
-            const int nw = (int)gridDim.x * NWG, me = (int)blockIdx.x * NWG + wv;
-            for (int b = T + 1 + me * 64 + lane; b <= a.flat_last; b += nw * 64) {
-                ((int*)flat_rec(a.f, a.flat_base + b, 0, 0))[22] = -1; ((int*)flat_rec(a.f, a.flat_base + b, 0, 1))[22] = -1;
-            }
+        // XCD-aware order: workgroups b, b + 8, ... share an XCD (and its L2); XCD x walks the band [x chunk, (x + 1) chunk) of the tiles
+        if constexpr (FLAT) {
+            ntile = __builtin_amdgcn_readfirstlane(flat_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
+                                                             a.tile_stride, vdesc, t0));
+            t0 = __builtin_amdgcn_readfirstlane(t0);
+        } else {
+            ntile = __builtin_amdgcn_readfirstlane(dense_fill(a.f, a.row_lo, a.row_hi, lane, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * NWG + wv,
+                                                              a.tile_stride, vdesc));
         }
     }
     if (ntile <= 0) return;
     int it = 0;
+    // flat: the arrival ticket of the tile just rendered and which of its two boundaries it arrived at (bit 0: the one before it, bit 1:
+    // the one behind it; 0: nothing pending).  The ticket is READ at the top of the next tile (or behind the loop): by then the output
+    // stores issued after the atomic have long completed, so the in-order vmcnt wait for it costs nothing.
+    // (ONE register across tiles: lanes 0 / 1 hold the tickets, lane 2 the pending bits, lane 3 the index of the boundary before that tile)
+    int ticket = 0;
     do {   // (one pass, and no loop at all for the compiler, when !PERSIST)
-    wave_prio<false>(!PERSIST || it + 1 >= ntile, true);
+    wave_prio<PERSIST && !FLAT>(it + 1 >= ntile, true);   // (flat: two equal tiles per wave, left alone: +1.9 % with it; one-tile dense: 1 % slower with it)
     KArgs* apk = ap;
-    if constexpr (PERSIST) asm volatile("" : "+s"(apk));
-    const FusedArgs a_copy = *(const FusedArgs*)apk;   // the arguments as values (see k_render_dense)
+    if constexpr (PERSIST) asm volatile("" : "+s"(apk));  // nothing read through apk is loop-invariant to the compiler
+    // The arguments as VALUES: the by-value kernel parameter when the wave renders one tile (the compiler fetches it in a few wide
+    // scalar loads at kernel entry), a copy made at the top of every tile of the walk (one burst of scalar loads, through the opaque
+    // pointer so that nothing of it lives across tiles).  Read field by field through the pointer instead, each use paid a scalar
+    // load and its wait where it stood: +2.5 % on a tile (c3 fp32 180.5 -> 176.0 us, c4 211.7 -> 206.9: profiles/r04/ab_kernarg_access.txt).
+    const FusedArgs a_copy = *(const FusedArgs*)apk;
     const FusedArgs& a = PERSIST ? a_copy : a_;
     const DevFrame& f = a.f;
+    // ... and so is everything per-lane: nothing derived from the lane index may be hoisted out of the tile loop either
     const int tid = PERSIST ? opaque((int)threadIdx.x) : (int)threadIdx.x;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wv = NWG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -2232,30 +2300,54 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
 #else
     unsigned* dbg = nullptr; (void)dbg;
 #endif
-    // ---- tile -> (first row, offset in that row); the rows the window covers ------------------------------------------------
     const unsigned desc = (unsigned)__builtin_amdgcn_readlane((int)vdesc, it);
     if (desc == 0xFFFFFFFFu) continue;
-    const int tile = t0 + it * a.tile_stride;        // this tile's index in the launch = the boundary behind it
-    const int r0 = (int)(desc >> 16), off0 = (int)(desc & 0xFFFFu);
-    if (r0 < a.row_lo || r0 >= a.row_hi) continue;
-    const int bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? r0 / f.H : 0);   // (one launch per batch item: every row of the window is its)
     typedef const int __attribute__((address_space(4))) kint;  // written by an earlier launch: scalar loads
-    const kint* kns = (const kint*)f.nsamp;
-    int cov = 0, my_row = r0, my_ent = 0;
-    bool have = false;
-    {
-        int rr = r0, eoff = off0;
-        while (cov < 32 && rr < a.row_hi) {   // (one or two rows in all but tiny maps)
-            const int ns = min(max(kns[rr], 0), f.smapStride - 32);
-            const int take = min(max(ns - eoff, 0), 32 - cov);
-            if (j >= cov && j < cov + take) { my_row = rr; my_ent = eoff + (j - cov); have = true; }
-            cov += take; ++rr; eoff = 0;
-        }
-    }
-    const int n = cov;
-    if (n <= 0) continue;
+    // ---- the window: its samples (lane j = sample j of it), its bundles [first, first + nb) as indices into the batch item's map --------
+    // dense: tile index -> (row, window); flat: tile -> (first row, offset in that row) and the rows the 32 samples cover.
+    // Everything read from the plan is clamped to the frame, so that a plan that does not belong to this frame's depth prior renders
+    // garbage instead of reading or writing outside the frame.
+    int bi, n, tile = 0, row_l = 0, my_row = 0;
     unsigned m = 0xFFFFFFFFu;
-    if (have) m = ldu<unsigned>(f.smap, 4u * (unsigned)(my_row * f.smapStride + my_ent));
+    bool have = true;
+    if constexpr (FLAT) {
+        tile = t0 + it * a.tile_stride;        // this tile's index in the launch = the boundary behind it
+        const int r0 = (int)(desc >> 16), off0 = (int)(desc & 0xFFFFu);
+        if (r0 < a.row_lo || r0 >= a.row_hi) continue;
+        bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? r0 / f.H : 0);   // (one launch per batch item: every row of the window is its)
+        const kint* kns = (const kint*)f.nsamp;
+        int cov = 0, my_ent = 0;
+        my_row = r0; have = false;
+        {
+            int rr = r0, eoff = off0;
+            while (cov < 32 && rr < a.row_hi) {   // (one or two rows in all but tiny maps)
+                const int ns = min(max(kns[rr], 0), f.smapStride - 32);
+                const int take = min(max(ns - eoff, 0), 32 - cov);
+                if (j >= cov && j < cov + take) { my_row = rr; my_ent = eoff + (j - cov); have = true; }
+                cov += take; ++rr; eoff = 0;
+            }
+        }
+        n = cov;
+        if (n <= 0) continue;
+        if (have) m = ldu<unsigned>(f.smap, 4u * (unsigned)(my_row * f.smapStride + my_ent));
+    } else {
+        const int rowid = (int)(desc >> 16), win = (int)(desc & 0xFFFFu);
+        if (rowid < a.row_lo || rowid >= a.row_hi) continue;
+        bi = __builtin_amdgcn_readfirstlane(f.B > 1 ? rowid / f.H : 0); row_l = rowid - bi * f.H;
+        const kint* krec = (const kint*)(f.plan + (size_t)rowid * (f.planMW + 2));
+        if (win >= krec[0]) continue;  // (cannot happen with a plan that belongs to this depth prior)
+        // This window = the row's sample offsets [s0, s0 + n), n <= 32, whole bundles (plan_row).
+        const int s0 = min(max(krec[1 + win], 0), f.smapStride - 32);
+        n = min(max(krec[2 + win] - s0, 0), 32);
+        if (n <= 0) continue;
+        m = ldu<unsigned>(f.smap + (size_t)rowid * f.smapStride, 4u * (unsigned)(s0 + j));  // lane j = sample s0 + j of the row
+    }
+    // flat: settle the previous tile's arrivals here - its output stores have had the window lookup above to complete (the in-order
+    // wait for the ticket waits for them), and the target camera's 24 scalars are not live yet
+    if constexpr (FLAT && PERSIST) {
+        const int pend = __builtin_amdgcn_readlane(ticket, 2);
+        if (pend) { flat_settle(a, f, ticket, pend, __builtin_amdgcn_readlane(ticket, 3), lane); ticket = 0; }
+    }
     float tc[TAR_STRIDE];
     {
         const kfloat* tcg = kptr(tar_cam(f, bi));
@@ -2264,32 +2356,46 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
         for (int i = 0; i < TAR_STRIDE; ++i) tc[i] = tcg[i];
     }
     STAMP(0);
-    const int mx = min((int)(m & 0xFFFFu), f.W - 1), k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
-    const int row_l = my_row - bi * f.H;             // this lane's bundle-map row inside its batch item
-    const int gbl = row_l * f.W + mx;                // ... and its bundle index inside the batch item's map (< 2^24, checked by the launcher)
-    // the window's bundles: lane 0's .. the last lane's; bundles hold >= 1 sample each, so they are consecutive map indices, <= 32
-    const int first = __builtin_amdgcn_readfirstlane(gbl);
-    const int nb = min(max(__builtin_amdgcn_readlane(gbl, n - 1) - first + 1, 0), 32);
-    if (nb <= 0 || first < 0 || first + nb > f.H * f.W) continue;
-    const bool act = have && m != 0xFFFFFFFFu && gbl - first >= 0 && gbl - first < nb && k_g < mcnt && mcnt >= 1 && mcnt <= f.S_max;
-    // does the window begin / end inside a bundle?  (its first sample is not slot 0 / its last sample is not the bundle's last)
-    const int hp = __builtin_amdgcn_readfirstlane(k_g) > 0 ? 1 : 0;
-    const int tp = (__builtin_amdgcn_readlane(k_g, n - 1) + 1 < __builtin_amdgcn_readlane(mcnt, n - 1)) ? 1 : 0;
+    int first, nb, hp = 0, tp = 0, mx;
+    const int k_g = (int)((m >> 16) & 0xFFu), mcnt = (int)(m >> 24);
+    bool act;
+    if constexpr (FLAT) {
+        mx = min((int)(m & 0xFFFFu), f.W - 1);
+        row_l = my_row - bi * f.H;                       // this lane's bundle-map row inside its batch item
+        const int gbl = row_l * f.W + mx;                // ... and its bundle index inside the batch item's map (< 2^24, checked by the launcher)
+        // the window's bundles: lane 0's .. the last lane's; bundles hold >= 1 sample each, so they are consecutive map indices, <= 32
+        first = __builtin_amdgcn_readfirstlane(gbl);
+        nb = min(max(__builtin_amdgcn_readlane(gbl, n - 1) - first + 1, 0), 32);
+        if (nb <= 0 || first < 0 || first + nb > f.H * f.W) continue;
+        act = have && m != 0xFFFFFFFFu && gbl - first >= 0 && gbl - first < nb && k_g < mcnt && mcnt >= 1 && mcnt <= f.S_max;
+        // does the window begin / end inside a bundle?  (its first sample is not slot 0 / its last sample is not the bundle's last)
+        hp = __builtin_amdgcn_readfirstlane(k_g) > 0 ? 1 : 0;
+        tp = (__builtin_amdgcn_readlane(k_g, n - 1) + 1 < __builtin_amdgcn_readlane(mcnt, n - 1)) ? 1 : 0;
+        // what has to survive gather + MLP in ONE register: map index (24 bits) | slot (4) | count - 1 (4)
+        m = (unsigned)gbl | ((unsigned)min(k_g, 15) << 24) | ((unsigned)(min(max(mcnt, 1), 16) - 1) << 28);
+    } else {
+        mx = (int)(m & 0xFFFFu);
+        // the window's bundles: first (lane 0's: a window starts at a bundle's first sample) .. the last lane's, nb <= 32
+        first = min(max(__builtin_amdgcn_readfirstlane(mx), 0), f.W - 1);
+        nb = min(max(__builtin_amdgcn_readlane(mx, n - 1) - first + 1, 0), min(32, f.W - first));
+        if (nb <= 0) continue;
+        const int bj_g = min(max(mx - first, 0), nb - 1);        // this sample's bundle inside the window (= its output column)
+        act = j < n && m != 0xFFFFFFFFu && mx - first >= 0 && mx - first < nb && j - k_g >= 0 && k_g < mcnt && mcnt <= f.S_max;
+        mx = first + bj_g;
+    }
     const float* mfg = a.pw + PW_FP32_FLOATS + (PREC == GDB_PREC_F32 ? MFMA_FLOATS : 0);
     const float b_agg = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BAGG : TS_BAGG], b_w2 = kptr(mfg)[PREC == GDB_PREC_F32 ? S32_BW2 : TS_BW2];
-    // what has to survive gather + MLP in ONE register: map index (24 bits) | slot (4) | count - 1 (4)
-    const unsigned m2 = (unsigned)gbl | ((unsigned)min(k_g, 15) << 24) | ((unsigned)(min(max(mcnt, 1), 16) - 1) << 28);
     float vox[4];
     {
         float z_g;
         Bundle<4> q;
         load_bundle<4, true, false>(f, tc, bi, row_l, mx, q);
-        q.count = min(max(mcnt, 1), f.S_max);
+        q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
         slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
     STAMP(2);
-    wave_prio<false>(!PERSIST || it + 1 >= ntile, false);
+    wave_prio<PERSIST && !FLAT>(it + 1 >= ntile, false);
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
     float v[22];  // 0..15 blended channels own_chan(h, i), 16..19 feat_head 4h.., 20 weight, 21 weight x depth
@@ -2303,11 +2409,20 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[16 + i] = fhv[i];
     }
-    // ---- composite across the lanes of a bundle (as k_render_dense) ---------------------------------------------------------
-    const unsigned m_c = (unsigned)opaque((int)m2);
-    const int gb = (int)(m_c & 0xFFFFFFu), k = (int)((m_c >> 24) & 0xFu), cnt = min((int)(m_c >> 28) + 1, f.S_max);
-    const int bj = min(max(gb - first, 0), nb - 1);
-    float z;
+    // ---- composite across the lanes of a bundle --------------------------------------------------------------------------
+    // The sample's slot, count and output column are decoded AGAIN from its list entry (one register across gather + MLP instead
+    // of four: the split-f16 build has none to spare).
+    const unsigned m_c = (unsigned)opaque((int)m);
+    int k, cnt, bj, gb;   // slot, count, the sample's bundle inside the window (= its output column), its index in the batch item's map
+    if constexpr (FLAT) {
+        gb = (int)(m_c & 0xFFFFFFu); k = (int)((m_c >> 24) & 0xFu); cnt = min((int)(m_c >> 28) + 1, f.S_max);
+        bj = min(max(gb - first, 0), nb - 1);
+    } else {
+        k = (int)((m_c >> 16) & 0xFFu); cnt = min(max((int)(m_c >> 24), 1), f.S_max);
+        bj = min(max((int)(m_c & 0xFFFFu) - first, 0), nb - 1);
+        gb = row_l * f.W + first + bj;
+    }
+    float z;  // the sample's depth, derived again from the depth prior (two loads the gather has left in L1 / L2) as bundle_sample does
     {
         const size_t hw = (size_t)f.H * f.W;
         const unsigned pz = 4u * (unsigned)gb;
@@ -2318,46 +2433,55 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
     }
     const float al = act ? alpha_of(__shfl(sig, j)) : 0.f;  // sigma sits in half 0
     const float zt = f.inv_depth ? 1.f / z : z;
-    // a straddling bundle's samples go to the side records of their boundary (the one before this tile for the window's first
-    // bundle, the one behind it for its last): k_flat_fix composites them
-    {
+    if constexpr (FLAT) {
+        // a straddling bundle's samples go to the side records of their boundary (the one before this tile for the window's first
+        // bundle, the one behind it for its last): whichever wave arrives last at the boundary composites them (below)
         const bool in_head = hp && bj == 0, in_tail = tp && bj == nb - 1;
         if (act && (in_head || in_tail)) {
             float* r = flat_rec(f, a.flat_base + tile + (in_head ? 0 : 1), k, h);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) ((float4*)r)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-            ((float2*)r)[10] = make_float2(al, zt);
-            if (in_tail && k == 0) { ((int*)r)[22] = gb; ((int*)r)[23] = cnt; }   // the boundary's header: map index, sample count
+            for (int i = 0; i < 5; ++i) store_sc1_16(r + 4 * i, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            // (the boundary's header - map index, sample count - rides in every record; the fix-up reads slot 0's, a tail-side sample)
+            store_sc1_16(r + 20, al, zt, __builtin_bit_cast(float, gb), __builtin_bit_cast(float, cnt));
         }
-        if (!tp && j == 0) ((int*)flat_rec(f, a.flat_base + tile + 1, 0, h))[22] = -1;   // no bundle straddles the boundary behind this tile
     }
     const int S = f.S_max;
     if (S <= 4) {
+        // An active sample's earlier samples are the lanes just below it in the same half (k <= j), a bundle's later samples the
+        // lanes just above (they end at lane 31 at the latest): whole-wave DPP shifts never carry a value across a bundle's edge
+        // that the predicates below do not mask.
         float Tr = 1.f, ap_ = al;
 #pragma unroll
-        for (int d = 1; d < 4; ++d) {
+        for (int d = 1; d < 4; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
             ap_ = wave_shr1(ap_);
             if (d <= k) Tr *= 1.f - ap_;
         }
         const float w = al * Tr;
 #pragma unroll
-        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
+        for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
         v[20] = w;
         v[21] = act ? w * zt : 0.f;
-        const bool is_cont = act && k > 0 && j > 0;   // (lane 32 = sample 0 of the other half: never a continuation of lane 31's bundle,
-                                                       // although its slot is > 0 when the window begins inside a bundle)
+        // Segmented suffix sums as a Horner chain: acc <- v + (the bundle has a next sample ? acc of the next lane : 0); after
+        // S - 1 steps the bundle's first lane (k == 0) holds the bundle's sums.  The neighbour is masked with a SELECT, not a
+        // multiply by 0: a non-finite sum of the next bundle must stay in its own bundle (as in the other schedules and the reference).
+        // (The select sits on the SOURCE lane - "I continue the bundle of the lane below" - so that the shift folds into the add:
+        // v_cndmask + v_add_f32_dpp, two instructions per value and step; profiles/r04/ab_single_changes_f32.txt has the earlier forms.)
+        // (flat: lane 32 = sample 0 of the other half is never a continuation of lane 31's bundle, although its slot is > 0 when the
+        // window begins inside a bundle)
+        const bool is_cont = FLAT ? (act && k > 0 && j > 0) : (act && k > 0);   // this lane continues the bundle of the lane below it
         float acc[22];
 #pragma unroll
         for (int i = 0; i < 22; ++i) acc[i] = v[i];
         for (int d = 1; d < S; ++d) {
 #pragma unroll
+            // mask at the SOURCE lane (a continuation lane: active, slot > 0), then one DPP add per value: acc <- v + shl(masked acc)
             for (int i = 0; i < 22; ++i) { const float mk = is_cont ? acc[i] : 0.f; acc[i] = v[i] + wave_shl1(mk); }
         }
 #pragma unroll
         for (int i = 0; i < 22; ++i) v[i] = acc[i];
     } else {
         float Tr = 1.f;
-        for (int d = 1; d < S; ++d) {
+        for (int d = 1; d < S; ++d) {  // transmittance: product over the bundle's earlier samples (lanes j-1 .. j-k)
             const float ap_ = __shfl_up(al, d, 32);
             if (d <= k) Tr *= 1.f - ap_;
         }
@@ -2366,7 +2490,7 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
         for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
         v[20] = w;
         v[21] = act ? w * zt : 0.f;
-        for (int d = 1; d < S; d <<= 1) {
+        for (int d = 1; d < S; d <<= 1) {  // segmented suffix sums by doubling (ds_bpermute): the bundle's first lane ends with its sums
             const bool take = act && k + d < cnt;
 #pragma unroll
             for (int i = 0; i < 22; ++i) {
@@ -2376,12 +2500,24 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
         }
     }
     STAMP(7);
+    // ---- flat: arrive at the boundaries this window shares with its neighbours (see "the hand-off" above) ----------------------------
+    // The wave's side records (issued before the composite above) have left the CU before its arrival is counted: the stores are
+    // inline asm, the compiler's own wait counting does not see them.  The returning atomic is only REQUESTED here; its value is read
+    // behind the output copy, whose stores do not delay it (loads / atomics return in issue order, and the copy is issued later).
+    if constexpr (FLAT) {
+        if (hp | tp) {   // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int* cp = f.side_hdr + a.flat_base + tile + (lane & 1);   // lane 0: the boundary before this tile, lane 1: the one behind it
+            ticket = lane == 2 ? (hp | (tp << 1)) : (lane == 3 ? a.flat_base + tile : 0);
+            if ((lane == 0 && hp) || (lane == 1 && tp)) ticket = __hip_atomic_fetch_add(cp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
-    // the window's WHOLE bundles (columns hp .. nb - 1 - tp) to the output record, column 0 = the first whole one
-    float* o = stage;
+    // the window's WHOLE bundles (columns hp .. nb - 1 - tp; dense: all of them) to the output record, column 0 = the first whole one
+    float* o = stage;  // the output record: [bundles of the window][ld] (+ depth, opacity behind it in the three-tensor form)
     const int ld = a.ldo, col = bj - hp, ncol = nb - hp - tp;
-    if (act && k == 0 && col >= 0 && col < ncol) {
+    if (act && k == 0 && (!FLAT || (col >= 0 && col < ncol))) {
         const float rden = 1.f / fmaxf(v[20], 1e-6f);
         out_store_own16(o, ld, col, h, [&](int i) { return v[i] * rden; });
 #pragma unroll
@@ -2394,85 +2530,27 @@ __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) {
     }
     __builtin_amdgcn_wave_barrier();
     PHASE_FENCE();
-    if (ncol > 0) out_copy(a, o, (size_t)bi * f.H * f.W + (size_t)(first + hp), ncol, lane);
-    STAMP(8); STAMP(9);
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (FLAT) { if (ncol > 0) out_copy(a, o, (size_t)bi * f.H * f.W + (size_t)(first + hp), ncol, lane); }
+    else out_copy(a, o, ((size_t)bi * f.H + row_l) * f.W + (size_t)first, nb, lane);
+    STAMP(8);
+    STAMP(9);
+    __builtin_amdgcn_wave_barrier();  // the next tile's gather overwrites the area the stores above read
     PHASE_FENCE();
     } while (PERSIST && ++it < ntile);
+    if constexpr (FLAT) {   // the last tile's arrival (every tile's, when the wave renders one)
+        const int pend = __builtin_amdgcn_readlane(ticket, 2);
+        if (pend) {
+            const FusedArgs& a = *(const FusedArgs*)ap;
+            flat_settle(a, a.f, ticket, pend, __builtin_amdgcn_readlane(ticket, 3), (int)(threadIdx.x & 63));
+        }
+    }
 }
 
-// The bundles that straddle a window boundary of the flat schedule, from the per-sample records both waves left: one wave per
-// boundary, lane (h, i) = lane half x value index (0..19 the weighted values, 20 the weight, 21 weight x depth term), EXACTLY the
-// in-wave composite's arithmetic: transmittance as the product over the earlier samples nearest first, weights alpha x T, the sums
-// right-nested (S_max <= 4: the Horner chain) or by doubling (S_max > 4: the ds_bpermute steps).
-// NS = slots unrolled (registers, all records requested up front: one memory round trip behind the header's): 4 for S_max <= 4, 16 else.
-// One wave takes FIX_PER_WAVE consecutive boundaries, all their records requested before the first is used (the kernel is a launch
-// ramp and two dependent memory round trips long, not arithmetic).  Measured again on the final kernels (same box, c2 fp32, render /
-// prepare + render on the HBM ring, us): 1 per wave 94.0 / 107.6, 2: 94.5 / 108.2, 3: 94.9 / 108.7, 4: 95.5 / 109.3, 8: 96.8.
-#ifndef FIX_PER_WAVE
-#define FIX_PER_WAVE 1
-#endif
-template <int NS>
-__global__ void __launch_bounds__(256) k_flat_fix(FusedArgs a) {
-#pragma clang fp contract(off)
-    const DevFrame& f = a.f;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-    const int S = f.S_max;
-    const int b0 = ((int)blockIdx.x * 4 + wv) * FIX_PER_WAVE + 1;   // boundary b sits behind tile b - 1 (those behind the list's end are marked empty)
-    float val[FIX_PER_WAVE][NS], alv[FIX_PER_WAVE][NS], ztv[FIX_PER_WAVE][NS];
-    int gbv[FIX_PER_WAVE], cntv[FIX_PER_WAVE];
-#pragma unroll
-    for (int q = 0; q < FIX_PER_WAVE; ++q) {
-        const int b = min(b0 + q, a.flat_last);   // (clamped: the grid's last wave may reach past the worst case; skipped below)
-        const float* r0 = flat_rec(f, a.flat_base + b, 0, h);
-        gbv[q] = ((const int*)r0)[22]; cntv[q] = ((const int*)r0)[23];   // the header rides in slot 0's padding (written by the tail side)
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {   // every slot the config can have, unconditionally (slots past the count are unused)
-            const float* r = r0 + (size_t)min(k, S - 1) * 2 * FLAT_REC;
-            alv[q][k] = r[20]; ztv[q][k] = r[21]; val[q][k] = r[i < 20 ? i : 0];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < FIX_PER_WAVE; ++q) {
-        const int gb = gbv[q], cnt = cntv[q];
-        if (b0 + q > a.flat_last || gb < 0 || cnt < 2 || cnt > S || cnt > NS || gb >= f.H * f.W) continue;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            float Tr = 1.f;
-#pragma unroll
-            for (int d = 1; d <= k; ++d) if (S > 4 ? d < S : d < 4) Tr *= 1.f - alv[q][k - d];
-            const float w = alv[q][k] * Tr;
-            val[q][k] = i < 20 ? w * val[q][k] : (i == 20 ? w : w * ztv[q][k]);
-        }
-        float acc;
-        if (S <= 4) {
-            acc = 0.f;
-            bool started = false;
-#pragma unroll
-            for (int k = NS - 1; k >= 0; --k)
-                if (k < cnt) { acc = started ? val[q][k] + acc : val[q][k]; started = true; }
-        } else {
-#pragma unroll
-            for (int d = 1; d < NS; d <<= 1)
-                if (d < S) {
-#pragma unroll
-                    for (int k = 0; k + d < NS; ++k) if (k + d < cnt) val[q][k] = val[q][k] + val[q][k + d];   // ascending k reads the not yet updated k + d
-                }
-            acc = val[q][0];
-        }
-        const float wsum = __shfl(acc, (h << 5) | 20), rden = 1.f / fmaxf(wsum, 1e-6f);
-        const size_t row = (size_t)(a.f.B > 1 ? a.row_lo / f.H : 0) * f.H * f.W + (size_t)gb;
-        int ch = -1;
-        if (i < 16) ch = own_chan(h, i);
-        else if (i < 20) ch = NBLEND + 4 * h + (i - 16);
-        if (ch >= 0) a.bf[row * a.ldo + ch] = acc * rden;
-        if (h == 0 && i == 20) { if (a.ldo == NOUT) a.opac[row] = acc * rden; else a.bf[row * a.ldo + NOUT + 1] = acc * rden; }
-        if (h == 0 && i == 21) {
-            const float d = acc * rden, dd = f.inv_depth ? 1.f / d : d;
-            if (a.ldo == NOUT) a.depth[row] = dd; else a.bf[row * a.ldo + NOUT] = dd;
-        }
-    }
-}
+template <int PREC, int WPS, int NWG, bool PERSIST>
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) { render_list_body<PREC, NWG, PERSIST, false>(a_); }
+template <int PREC, int WPS, int NWG, bool PERSIST>
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) { render_list_body<PREC, NWG, PERSIST, true>(a_); }
+
 
 // LDS above 64 KB per workgroup needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
 // function: the once-flag is a bit per device ordinal (relaxed atomics; setting it twice is harmless).
@@ -2535,7 +2613,10 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0}, done1{0};
     static std::atomic<unsigned long long> resident[64];
     hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG, true>, done);
+#ifdef GDB_DIAG   // (the one-tile-per-wave form exists in the diagnostic build only: GDB_SCHED_AUTO always walks)
     if (e == hipSuccess) e = allow_big_lds(k_render_dense<PREC, WPS, NWG, false>, done1);
+#endif
+    (void)done1;
     if (e != hipSuccess) return e;
     int per_cu = 1, cus = 1;
     e = resident_workgroups(k_render_dense<PREC, WPS, NWG, true>, 64 * NWG, NWG * lds, resident, per_cu, cus);
@@ -2577,8 +2658,11 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
 #endif
         if (!persist) g = worst;
         a.tile_stride = (int)(g >> 3) * NWG;
-        if (persist) hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, true>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
-        else hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+#ifdef GDB_DIAG
+        if (!persist) hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        else
+#endif
+        hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, true>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2596,8 +2680,8 @@ static hipError_t launch_dense(FusedArgs& a, size_t lds, hipStream_t st) {
     return launch_dense_n<PREC, WPS, 1>(a, lds, st);
 }
 
-// Flat schedule: one launch of k_render_flat per batch item (a window never crosses batch items), then k_flat_fix for the bundles
-// that straddle a window boundary.  Grid and walk / one-tile rule as launch_dense_n.
+// Flat schedule: one launch of k_render_flat per batch item (a window never crosses batch items); the bundles that straddle a window
+// boundary are composited inside the same launch by whichever of their two waves arrives last (flat_fix_boundary).  Grid as launch_dense_n.
 template <int PREC, int WPS, int NWG>
 static hipError_t launch_flat_n(FusedArgs& a, size_t lds, int max_tiles_per_item, hipStream_t st) {
     // (the split-f16 build at three waves per SIMD has no register left for the walk's loop state: one tile per wave there)
@@ -2605,7 +2689,10 @@ static hipError_t launch_flat_n(FusedArgs& a, size_t lds, int max_tiles_per_item
     static std::atomic<unsigned long long> done{0}, done1{0};
     static std::atomic<unsigned long long> resident[64];
     hipError_t e = allow_big_lds(k_render_flat<PREC, WPS, NWG, CAN_WALK>, done);
+#ifdef GDB_DIAG
     if (e == hipSuccess) e = allow_big_lds(k_render_flat<PREC, WPS, NWG, false>, done1);
+#endif
+    (void)done1;
     if (e != hipSuccess) return e;
     int per_cu = 1, cus = 1;
     e = resident_workgroups(k_render_flat<PREC, WPS, NWG, CAN_WALK>, 64 * NWG, NWG * lds, resident, per_cu, cus);
@@ -2621,25 +2708,22 @@ static hipError_t launch_flat_n(FusedArgs& a, size_t lds, int max_tiles_per_item
         a.row_hi = a.row_lo + a.nrows;
         a.flat_base = bi * (max_tiles_per_item + 1);
         const long long tiles = ((long long)a.nrows * a.f.W * a.f.S_max + 31) / 32 + 1;   // worst case: every bundle at S_max
-        a.flat_last = (int)tiles;   // boundaries 1 .. tiles (boundary b sits behind tile b - 1); the workspace holds max_tiles_per_item + 1 >= tiles + 1 of them
         const long long worst = ((tiles + NWG - 1) / NWG + 7) / 8 * 8;
         long long g = grid > worst ? worst : grid;
         const long long need = 8 * (((tiles + 7) / 8 + 64LL * NWG - 1) / (64LL * NWG));   // at most 64 tiles per wave (one descriptor per lane)
         if (g < need) g = need;
-        bool persist = CAN_WALK && (tiles <= 3 * grid * NWG || a.f.S_max > 4);   // (launch_dense_n's rule)
+        bool persist = CAN_WALK;   // (always the walk where the build can, as launch_dense_n)
 #ifdef GDB_DIAG
         static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
         if (env_persist >= 0) persist = CAN_WALK && env_persist != 0;
 #endif
         if (!persist) g = worst;
         a.tile_stride = (int)(g >> 3) * NWG;
-        if (persist) hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, CAN_WALK>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
-        else hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const unsigned fix_grid = (unsigned)((tiles + 4 * FIX_PER_WAVE - 1) / (4 * FIX_PER_WAVE));
-        if (a.f.S_max <= 4) hipLaunchKernelGGL(k_flat_fix<4>, dim3(fix_grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_flat_fix<GDB_MAX_SAMPLES>, dim3(fix_grid), dim3(256), 0, st, a);
+#ifdef GDB_DIAG
+        if (!persist && CAN_WALK) hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        else
+#endif
+        hipLaunchKernelGGL((k_render_flat<PREC, WPS, NWG, CAN_WALK>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2668,20 +2752,65 @@ static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t
 // one-wave workgroups a CU holds by LDS (allocated in 1280-byte granules out of 160 KiB)
 static size_t waves_by_lds(size_t lds) { return (size_t)(160 * 1024) / ((lds + 1279) / 1280 * 1280); }
 
+// Compute units of the current device, asked once per device ordinal (relaxed; two threads racing just ask twice).
+static int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+// LDS per wave of the one-wave schedules (segment wave, dense, flat): the views' staging rows, or the output record where that is larger
+static size_t solo_lds_bytes(int prec, int V) {
+    const size_t sv = prec == GDB_PREC_F16 ? stage_v<GDB_PREC_F16>() : stage_v<GDB_PREC_F32>();
+    const size_t per_wave = sizeof(float) * (size_t)V * sv, rec = sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
+    return per_wave > rec ? per_wave : rec;
+}
+// Shape limits of the two list schedules.  Dense lists bundles and rows in 16 bits.  Flat: its descriptors pack a row (16 bits) with a
+// sample offset inside the row (16 bits), its lanes a map index (24 bits) with slot and count (4 + 4 bits), and the sample list is
+// addressed with one 32-bit byte offset.
+static bool dense_fits(const GdbFrame& fr) { return fr.W < 65536 && (long long)fr.B * fr.H < 65536; }
+static bool flat_fits(const GdbConfig& cfg, const GdbFrame& fr, const WsLayout& L) {
+    const int S = cfg.max_num_samples;
+    return dense_fits(fr) && (long long)fr.W * S < 65536 && (long long)fr.H * fr.W < (1 << 24) && S <= 16 &&
+           (unsigned long long)fr.B * fr.H * (unsigned long long)L.smapStride * 4ull < (1ull << 32);
+}
+// The ONE place that decides what a fused render call runs: `sched` as the caller passed it (GDB_SCHED_AUTO .. GDB_SCHED_FLAT) -> the
+// schedule launched (GDB_SCHED_SLOT_WAVES .. GDB_SCHED_FLAT).  gdb_render_info() exports it (bench.py, HotPathEngine: no second copy of
+// the rule in Python).  Measured choices (MI355X; profiles/r01/schedules.txt, r03/schedules.txt, r04/ab_*.txt, r05/ab_*.txt):
+//  * slot waves   - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Fixed counts, S_max <= 3.
+//  * segment wave - one wave walks all slots of its segment, composite in registers.  Fixed counts with S_max > 3 at f16 or with > 3 views.
+//  * dense        - the compacted sample list, one wave per window of whole bundles holding <= 32 samples.  Adaptive counts (the slot
+//                   schedules leave lanes idle: c2 80 % of the slot lanes busy, c4 44 %), and fixed counts per gdb_fixed_counts_dense.
+//  * flat         - windows of exactly 32 consecutive samples (4-8 % fewer waves; straddling bundles composited by the last arriver).
+//                   fp32 on frames of few tiles per wave slot with S_max <= 4 - c2: 8 % fewer tiles (6,112 instead of 6,631); not on
+//                   c3 / c4 (greedy windows already fill 96 % of the lanes: 182.5 vs 176.0, 227.8 vs 204.2 us).
+static int resolve_schedule(const GdbConfig& cfg, const GdbFrame& fr, const WsLayout& L, int prec, int nrows, int sched) {
+    const int S = cfg.max_num_samples, V = fr.V;
+    const bool one_wave_fits = solo_lds_bytes(prec, V) <= (size_t)160 * 1024;
+    const long long slots = 12LL * device_cus();   // resident wave slots at three waves per SIMD
+    const bool flat_wins = prec == GDB_PREC_F32 && S <= 4 && ((long long)nrows * fr.W * S + 31) / 32 + 1 <= 3 * slots;   // worst case <= 3 tiles per wave slot
+    if (one_wave_fits) {
+        if (sched == GDB_SCHED_FLAT || (sched == GDB_SCHED_AUTO && cfg.is_adaptive && flat_fits(cfg, fr, L) && flat_wins)) return GDB_SCHED_FLAT;
+        if (sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && dense_fits(fr) &&
+                                         (cfg.is_adaptive || (prec != GDB_PREC_F16 && gdb_fixed_counts_dense(cfg, V))))) return GDB_SCHED_DENSE;
+        if (sched == GDB_SCHED_SEGMENT_WAVE || (sched == GDB_SCHED_AUTO && S > 3)) return GDB_SCHED_SEGMENT_WAVE;
+    }
+    return GDB_SCHED_SLOT_WAVES;
+}
+
 template <int PREC>
-static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const void* ws, int sched, bool plan_ready, hipStream_t st) {
+static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const WsLayout& L, const void* ws, int sched, bool plan_ready, hipStream_t st) {
     const int S = cfg->max_num_samples, V = fr->V;
     const size_t per_wave = sizeof(float) * (size_t)V * stage_v<PREC>();
     const size_t lds_max = 160 * 1024;
     const bool rec_fits = per_wave >= sizeof(float) * COMP_REC;
     hipError_t e = hipSuccess;
-    // Two schedules (measured on MI355X, profiles/r01/schedules.txt):
-    //  * slot waves  - a workgroup is one segment x S waves, one sample slot each, composite through LDS.  Best when
-    //                  most slots hold a sample: S_max = 3 (c2, 80 % of the lanes active: 62 vs 72 us; c3 105 vs 126 us).
-    //  * segment wave - one wave walks all slots of its segment, composite in registers.  Best when slots are sparsely
-    //                  filled or the S-wave workgroup is LDS-limited: c4 (S_max 6 adaptive) 171 vs 296 us, c5 1346 vs 1490 us.
-    const bool want_solo = sched == GDB_SCHED_SEGMENT_WAVE || (sched == GDB_SCHED_AUTO && S > 3);
-    const size_t solo_lds = per_wave > sizeof(float) * (size_t)(NOUT + 2) * COMP_LD ? per_wave : sizeof(float) * (size_t)(NOUT + 2) * COMP_LD;
+    const size_t solo_lds = solo_lds_bytes(PREC, V);
     a.ntiles = a.nsegs;
     unsigned grid = (unsigned)((a.ntiles + 7) / 8 * 8);
     size_t pad = 0;
@@ -2689,43 +2818,12 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
     static const size_t env_pad = getenv("GDB_FUSED_LDS_PAD") ? (size_t)atol(getenv("GDB_FUSED_LDS_PAD")) : 0;
     pad = env_pad;
 #endif
-    // Dense: the compacted sample list, one wave per <= 32 consecutive samples (needs the plan built from the depth prior).
-    // Taken for adaptive counts, where the slot schedules leave lanes idle (c2, S_max 3: 80 % of the slot lanes busy, c4, S_max 6:
-    // 44 %).  Measured on MI355X (profiles/r03/schedules.txt), dense vs slot waves at f32: c2 103 vs 116 us, c3 183 vs 196,
-    // c3' 215 vs 240; f16 / split-f16 on c2: 56.3 vs 56.5, 70.1 vs 71.0 (round 2's dense schedule lost on c2: its per-wave
-    // count / scan / LDS-map prologue, a ds_bpermute composite, and a grid with dead workgroups between live ones).
-    const bool dense_fits = fr->W < 65536 && (long long)fr->B * fr->H < 65536;
-    // Flat: windows of 32 consecutive samples of the compacted list (bundles may straddle windows; k_flat_fix).  Its descriptors pack a
-    // row (16 bits) with a sample offset inside the row (16 bits), its lanes a map index (24 bits) with slot and count (4 + 4 bits),
-    // and the sample list is addressed with one 32-bit byte offset.
-    const bool flat_fits = dense_fits && (long long)fr->W * S < 65536 && (long long)fr->H * fr->W < (1 << 24) && S <= 16 &&
-                           (unsigned long long)fr->B * fr->H * (unsigned long long)(a.f.smapStride) * 4ull < (1ull << 32);
-    // GDB_SCHED_AUTO takes it where it measured faster than the window plan (profiles/r04/ab_dense_vs_flat.txt, same box, kernel us
-    // incl. the 5 us fix-up launch): fp32 on frames of few tiles per wave slot with S_max <= 4 - c2: 96.5 vs 99.8 (8 % fewer tiles:
-    // 6,112 instead of 6,631).  Not at f16 / split-f16 (a tile is half as long, the fix-up launch weighs twice: c2 f16 54.0 vs 50.9),
-    // not on c3 / c4 (greedy windows already fill 96 % of the lanes: 182.5 vs 176.0, 227.8 vs 204.2).
-    const bool flat_wins = PREC == GDB_PREC_F32 && S <= 4 &&
-                           ((long long)a.nrows * fr->W * S + 31) / 32 + 1 <= 3LL * 3072;   // (worst case <= 3 tiles per wave slot of a 256-CU part)
-    const bool want_flat = sched == GDB_SCHED_FLAT || (sched == GDB_SCHED_AUTO && cfg->is_adaptive && flat_fits && flat_wins);
-    if (want_flat && solo_lds <= lds_max) {
-        if (!flat_fits) return gdb_fail(GDB_E_SHAPE, "the flat schedule needs W x S_max < 65536, B x H < 65536, H x W < 2^24 (W = %d, H = %d, B = %d, S_max = %d)", fr->W, fr->H, fr->B, S);
-        if (!plan_ready) {
-            int rc = gdb_build_dense_plan(cfg, fr, const_cast<void*>(ws), st);
-            if (rc) return rc;
-        }
-        a.alias = 0;
-        const int max_tiles = (int)(((long long)fr->H * fr->W * S + 31) / 32 + 1);
-        bool three = false;
-        if constexpr (PREC != GDB_PREC_F32) three = waves_by_lds(solo_lds + pad) > 8 || 2 * waves_by_lds(2 * (solo_lds + pad)) > 8;
-        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_flat<PREC, 3>(a, (solo_lds + pad + 15) / 16 * 16, max_tiles, st); }
-        if (!three) e = launch_flat<PREC, 2>(a, (solo_lds + pad + 15) / 16 * 16, max_tiles, st);
-        if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_flat: %s", hipGetErrorString(e));
-        return GDB_OK;
-    }
-    const bool want_dense = sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && dense_fits &&
-                            (cfg->is_adaptive || (PREC != GDB_PREC_F16 && gdb_fixed_counts_dense(*cfg, V))));
-    if (want_dense && solo_lds <= lds_max) {
-        if (!dense_fits) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
+    const int run = resolve_schedule(*cfg, *fr, L, PREC, a.nrows, sched);
+    if (run == GDB_SCHED_FLAT || run == GDB_SCHED_DENSE) {
+        if (run == GDB_SCHED_FLAT && !flat_fits(*cfg, *fr, L))
+            return gdb_fail(GDB_E_SHAPE, "the flat schedule needs W x S_max < 65536, B x H < 65536, H x W < 2^24 (W = %d, H = %d, B = %d, S_max = %d)", fr->W, fr->H, fr->B, S);
+        if (run == GDB_SCHED_DENSE && !dense_fits(*fr))
+            return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
         // The plan + sample list are built here, into the plan region of the caller's workspace (a launch of its own on the same
         // stream), unless the caller vouches that gdb_prepare built them from the depth prior as it stands (GDB_SCHED_PLAN_READY).
         if (!plan_ready) {
@@ -2733,14 +2831,22 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
             if (rc) return rc;
         }
         a.alias = 0;
-        a.ntiles = a.nrows * a.f.planMW;  // per batch item, worst case (every bundle at S_max)
-        grid = (unsigned)((a.ntiles + 7) / 8 * 8);
         // the 3-waves-per-SIMD build (168 registers) wherever LDS admits more than the 8 waves per CU of the 2-wave build
         bool three = false;
         if constexpr (PREC != GDB_PREC_F32) three = waves_by_lds(solo_lds + pad) > 8 || 2 * waves_by_lds(2 * (solo_lds + pad)) > 8;
-        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, (solo_lds + pad + 15) / 16 * 16, st); }
-        if (!three) e = launch_dense<PREC, 2>(a, (solo_lds + pad + 15) / 16 * 16, st);
-    } else if (want_solo && solo_lds <= lds_max) {  // one wave per segment, all slots in turn
+        const size_t lds = (solo_lds + pad + 15) / 16 * 16;
+        if (run == GDB_SCHED_FLAT) {
+            const int max_tiles = (int)(((long long)fr->H * fr->W * S + 31) / 32 + 1);
+            if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_flat<PREC, 3>(a, lds, max_tiles, st); }
+            if (!three) e = launch_flat<PREC, 2>(a, lds, max_tiles, st);
+            if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_flat: %s", hipGetErrorString(e));
+            return GDB_OK;
+        }
+        a.ntiles = a.nrows * a.f.planMW;  // per batch item, worst case (every bundle at S_max)
+        grid = (unsigned)((a.ntiles + 7) / 8 * 8);
+        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, lds, st); }
+        if (!three) e = launch_dense<PREC, 2>(a, lds, st);
+    } else if (run == GDB_SCHED_SEGMENT_WAVE) {  // one wave per segment, all slots in turn
         a.alias = 0;
         // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
         bool three = false;
@@ -2762,6 +2868,21 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
         e = launch_fused<true, 4, PREC>(a, grid, nw, lds, st);
     }
     if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_fused: %s", hipGetErrorString(e));
+    return GDB_OK;
+}
+
+// What a fused render call would do for this (config, frame shape, precision, row strip), without launching anything (ABI v6).
+extern "C" int gdb_render_info(const GdbConfig* cfg, const GdbFrame* fr, int32_t precision, int32_t row_begin, int32_t row_end, int32_t out[4]) {
+    int rc = gdb_check_cfg(cfg); if (rc) return rc;
+    rc = gdb_check_frame(cfg, fr, false); if (rc) return rc;
+    if (!out) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X) return gdb_fail(GDB_E_BADARG, "precision %d unsupported", precision);
+    if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
+    const WsLayout L = ws_layout(*cfg, *fr);
+    out[0] = (cfg->bundle_size == 2 && fr->V >= 2) ? 1 : 0;
+    out[1] = out[0] ? resolve_schedule(*cfg, *fr, L, precision, row_end - row_begin, GDB_SCHED_AUTO) : 0;
+    out[2] = (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, fr->V)) ? 1 : 0;   // gdb_prepare builds the plan when the frame carries d_depth_range (gdb_ops.hip prepare_common)
+    out[3] = out[0] ? ((out[1] == GDB_SCHED_FLAT || (out[1] == GDB_SCHED_DENSE && fr->B > 1 && !(row_begin == 0 && row_end == fr->H))) ? fr->B : 1) : 0;
     return GDB_OK;
 }
 
@@ -2795,7 +2916,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
-    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1; a.flat_base = 0; a.flat_last = 0;
+    a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1; a.flat_base = 0;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     a.skip = env_skip; a.dbg = g_dbg;
@@ -2808,9 +2929,9 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
         rc = gdb_build_pyr16(cfg, fr, const_cast<void*>(ws), st);
         if (rc) return rc;
     }
-    if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, ws, schedule, plan_ready, st);
-    if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, ws, schedule, plan_ready, st);
-    return render_launch<GDB_PREC_F16>(a, cfg, fr, ws, schedule, plan_ready, st);
+    if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, L, ws, schedule, plan_ready, st);
+    if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, L, ws, schedule, plan_ready, st);
+    return render_launch<GDB_PREC_F16>(a, cfg, fr, L, ws, schedule, plan_ready, st);
 }
 
 extern "C" int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* fr, const void* ws, const float* pw,

@@ -79,6 +79,7 @@ struct WsLayout {
     int flatMaxTiles;   // flat schedule: windows of 32 consecutive samples at most (every bundle at S_max), per launch
     size_t pyr16Off;    // the half-precision copy of the feature pyramid the GDB_PREC_F16 render gathers from (PYR16_* below):
                         // 2 bytes per float of the fp32 pyramid, same (batch, view) stride and level offsets in elements
+    size_t img16Off;    // the half-precision RGBA copy of the source images (IMG16_* below) behind it: at IMG16_REL(...) from pyr16Off
 };
 
 // ---- half-precision pyramid (GDB_PREC_F16 only) ------------------------------------------------------------------------------
@@ -89,6 +90,16 @@ struct WsLayout {
 // two 16-byte loads and an 8-byte load of the fp32 pyramid - a third fewer load instructions, half the bytes through L1.
 // Values are the fp32 pyramid's, rounded to nearest half once (the mip levels are box-filtered in fp32 first).
 #define PYR16_PLANE2(hw) (32u * (unsigned)(hw))   // byte offset of plane 2 inside a level of hw texels (plane 1 sits at 16 hw)
+// Plane 2 is read as x PAIRS (one 16-byte load = channels 16..19 of texels x, x + 1: two loads per level instead of four): the pair of
+// the last texel of the last level reaches 8 bytes past the pyramid, so the region ends in PYR16_PAD bytes that gdb_prepare zeroes.
+#define PYR16_PAD 16
+// ---- half-precision source images (GDB_PREC_F16 only) -------------------------------------------------------------------------
+// Per (batch, view) Ho x Wo pixels of 8 bytes = halves (r, g, b, 0): an x pair of a colour tap is ONE 16-byte load where the planar
+// fp32 images (B,V,3,Ho,Wo) take three 8-byte ones (12 -> 4 colour loads per sample, view and lane: the f16 kernels are bound by the
+// texture addresser, profiles/r05/pmc_c5_f16_baseline.txt).  Values = the source colours rounded to nearest half once (they are in
+// [0, 1]: <= 2.4e-4), written by k_prepare (GDB_PREP_PYR16).  It sits behind the half-precision pyramid, at a distance both the host
+// and the kernels derive from the frame's sizes (no pointer of its own in the kernel arguments).
+#define IMG16_REL(pyrStride, BV) ((((size_t)2 * (size_t)(pyrStride) * (size_t)(BV)) + PYR16_PAD + 255) / 256 * 256)
 
 #define SCAN_BLOCK 1024
 // flat schedule: floats per (sample, lane half) record of a straddling bundle: 20 pre-weight values (16 blended + 4 feat_head),
@@ -145,7 +156,8 @@ static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
     L.flatMaxTiles = (int)((size_t)f.B * (((size_t)f.H * f.W * c.max_num_samples + 31) / 32 + 2));   // per batch item: tiles + 1 boundaries
     L.sideHdrOff = off; off = align_up(off + sizeof(int32_t) * 2 * ((size_t)L.flatMaxTiles + 1), 256);
     L.sideOff = off; off = align_up(off + sizeof(float) * FLAT_REC * 2 * (size_t)c.max_num_samples * ((size_t)L.flatMaxTiles + 1), 256);
-    L.pyr16Off = off; off = align_up(off + (size_t)2 * L.pyrStride * f.B * f.V, 256);
+    L.pyr16Off = off; off += IMG16_REL(L.pyrStride, (size_t)f.B * f.V);
+    L.img16Off = off; off = align_up(off + (size_t)8 * f.B * f.V * f.Ho * f.Wo + 16, 256);
     L.total = off;
     return L;
 }
@@ -303,9 +315,13 @@ __device__ __forceinline__ void load_ranges(const DevFrame& f, int bi, int h, in
 // pre: ranges already loaded by the caller (load_ranges), or nullptr
 // COUNT: derive the sample count from the ranges (bundle_sampler.py:179); false leaves q.count to the caller (the dense schedule
 // reads it from the plan's sample list)
+// (contraction off in the three geometry functions below: the mirrors' translation units have it off anyway; in the fused kernels'
+// (-ffp-contract=fast) it keeps every instantiation on the same bits - gdb_fused.hip, tex_coord_f - and the fused multiply-adds that
+// path wants are written out under FAST)
 template <int BB, bool FAST = false, bool COUNT = true>
 __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<BB>& q,
                                             const float* pre = nullptr) {
+#pragma clang fp contract(off)
     constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
     float sum[3] = {0.f, 0.f, 0.f};
     float su = 0.f, sv = 0.f;
@@ -314,7 +330,10 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __re
 #pragma unroll
         for (int bx = 0; bx < b; ++bx) {
             float x = (float)(w * b + bx) + 0.5f, y = (float)(h * b + by) + 0.5f;
-            ray_dir(tc + T_M, x, y, q.d[by * b + bx]);
+            if constexpr (FAST) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) q.d[by * b + bx][i] = fmaf(tc[T_M + 3 * i], x, fmaf(tc[T_M + 3 * i + 1], y, tc[T_M + 3 * i + 2]));
+            } else ray_dir(tc + T_M, x, y, q.d[by * b + bx]);
 #pragma unroll
             for (int i = 0; i < 3; ++i) sum[i] += q.d[by * b + bx][i];
             su += gdiv<FAST>(2.f * x, (float)f.Wo) - 1.f;
@@ -324,8 +343,9 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __re
 #pragma unroll
     for (int i = 0; i < 3; ++i) { md[i] = sum[i] / (float)BB; q.o[i] = tc[T_O + i]; }
     q.u = su / (float)BB; q.v = sv / (float)BB;
-    float nrm = sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
-    float cosv = gdiv<FAST>(md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2], nrm);
+    float nrm = FAST ? sqrtf(fmaf(md[2], md[2], fmaf(md[1], md[1], md[0] * md[0]))) : sqrtf(md[0] * md[0] + md[1] * md[1] + md[2] * md[2]);
+    float cosv = FAST ? gdiv<FAST>(fmaf(md[2], tc[T_Z + 2], fmaf(md[1], tc[T_Z + 1], md[0] * tc[T_Z])), nrm)
+                      : gdiv<FAST>(md[0] * tc[T_Z] + md[1] * tc[T_Z + 1] + md[2] * tc[T_Z + 2], nrm);
     q.unit = FAST ? ball_unit_fast(tc[T_DISK], cosv) : ball_unit(tc[T_DISK], cosv);
     float n0 = pre ? pre[0] : 0.f, f0 = pre ? pre[1] : 0.f, vn = pre ? pre[2] : 0.f, vf = pre ? pre[3] : 0.f;
     if (!pre) {
@@ -347,8 +367,9 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, in
 // time from the depth prior instead of keeping it in a register across gather + MLP.  bundle_sampler.py:183, :246
 template <bool FAST>
 __device__ __forceinline__ float sample_mid(float nearv, float farv, int count, int k) {
+#pragma clang fp contract(off)
     float step = gdiv<FAST>(farv - nearv, (float)count);
-    float t0 = nearv + step * (float)k, t1 = nearv + step * (float)(k + 1);
+    float t0 = FAST ? fmaf(step, (float)k, nearv) : nearv + step * (float)k, t1 = FAST ? fmaf(step, (float)(k + 1), nearv) : nearv + step * (float)(k + 1);
     return 0.5f * (t0 + t1);
 }
 
@@ -356,6 +377,7 @@ __device__ __forceinline__ float sample_mid(float nearv, float farv, int count, 
 template <int BB, bool FAST = false>
 __device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB>& q, int k, float& z, float& dnorm,
                                               float xyz[BB][3], float ctr[3], float& ball) {
+#pragma clang fp contract(off)
     z = sample_mid<FAST>(q.nearv, q.farv, q.count, k);                           // :183, :246
     dnorm = gdiv<FAST>(2.f * (z - q.vnear), q.vfar - q.vnear) - 1.f;             // :247
     if (f.inv_depth) z = gdiv<FAST>(1.f, z);                                     // :250-251
@@ -363,10 +385,10 @@ __device__ __forceinline__ void bundle_sample(const DevFrame& f, const Bundle<BB
 #pragma unroll
     for (int r = 0; r < BB; ++r)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { xyz[r][i] = q.o[i] + q.d[r][i] * z; s[i] += xyz[r][i]; }  // :255
+        for (int i = 0; i < 3; ++i) { xyz[r][i] = FAST ? fmaf(q.d[r][i], z, q.o[i]) : q.o[i] + q.d[r][i] * z; s[i] += xyz[r][i]; }  // :255
     float dd = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ctr[i] = s[i] / (float)BB; float e = ctr[i] - q.o[i]; dd += e * e; }  // :256,:259
+    for (int i = 0; i < 3; ++i) { ctr[i] = s[i] / (float)BB; float e = ctr[i] - q.o[i]; dd = FAST ? fmaf(e, e, dd) : dd + e * e; }  // :256,:259
     ball = sqrtf(dd) * q.unit;                                                   // :263
 }
 

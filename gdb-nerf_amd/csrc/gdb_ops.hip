@@ -224,9 +224,18 @@ struct PrepArgs {
     float* cams;
     // dense-schedule plan: workgroups ntiles+1 .. ntiles+nplan, one wave per bundle-map row
     int nplan, S_max, adaptive, planL, planMW;
+    int plan_r0, plan_nr;   // the plan covers the bundle-map rows [plan_r0, plan_r0 + plan_nr) of every batch item (gdb_prepare_rows: one rank's strip)
     const float* depth_range; int* plan;
     unsigned* smap; int smapStride; int* nwin; int* nsamp;
+    char* img16; int nimg;           // half-precision RGBA copy of the source images (gdb_internal.h IMG16_*): nimg workgroups of 512 pixels, or 0
+    int* flat_cnt; int n_flat_cnt;   // flat schedule: the window boundaries' arrival counters, zeroed here once per frame (gdb_fused.hip: hand-off)
 };
+// The plan workgroups also clear the flat schedule's arrival counters (a render leaves them at zero again: the last arriver of a
+// boundary resets it; this is what bounds the damage of a render that was aborted half-way).  nwg workgroups of 256 threads share the array.
+__device__ __forceinline__ void zero_flat_counters(const PrepArgs& a, int wg, int nwg) {
+    const int per = (a.n_flat_cnt + nwg - 1) / nwg, lo = wg * per, hi = min(a.n_flat_cnt, lo + per);
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) a.flat_cnt[i] = 0;
+}
 
 // One wave per bundle-map row: per-bundle sample counts (bundle_sampler.py:179), their exclusive prefix along the row, the row's
 // compacted sample list (WsLayout::smapOff: entry s = [bundle | slot << 16 | count << 24], bundle-major / sample-minor as
@@ -364,6 +373,23 @@ __device__ __forceinline__ void store16_chunk(char* __restrict__ base, unsigned 
     *(h4v*)(base + off) = to_h4(q);
 }
 
+// The half-precision RGBA copy of the source images (GDB_PREC_F16 renders take their colour taps from it): one thread per x pair of
+// pixels - three 8-byte loads (planar fp32), one 16-byte store (r, g, b, 0 | r, g, b, 0 as halves).  Wo is even (Wo = b W).
+__device__ __forceinline__ void img16_block(const float* __restrict__ src_images, char* __restrict__ img16, int nbv, int Ho, int Wo, int blk) {
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    const size_t plane = (size_t)Ho * Wo, pairs = plane / 2;
+    const size_t q = (size_t)blk * 256 + threadIdx.x;
+    if (q >= pairs * (size_t)nbv) return;
+    const size_t bv = q / pairs, p = (q - bv * pairs) * 2;   // first pixel of the pair inside the image
+    const float* im = src_images + bv * 3 * plane + p;
+    const float2 r = *(const float2*)im, g = *(const float2*)(im + plane), b = *(const float2*)(im + 2 * plane);
+    const h8v o = {(_Float16)r.x, (_Float16)g.x, (_Float16)b.x, (_Float16)0.f, (_Float16)r.y, (_Float16)g.y, (_Float16)b.y, (_Float16)0.f};
+    *(h8v*)(img16 + (bv * plane + p) * 8) = o;
+}
+__global__ void __launch_bounds__(256) k_img16(const float* __restrict__ src_images, char* __restrict__ img16, int nbv, int Ho, int Wo) {
+    img16_block(src_images, img16, nbv, Ho, Wo, (int)blockIdx.x);
+}
+
 __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     __shared__ float4 tile4[PT_W * PT_H * (GDB_CP / 4)];  // level 0 of the tile, [chunk][y][x]
     static_assert(sizeof(tile4) >= 4 * 128 * sizeof(unsigned) && PLAN_LDS_ROW <= 128 * 32, "the plan rows borrow the tile's LDS: 128 words of start bits per row");
@@ -372,18 +398,22 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
     // scattered stores); dispatched last they ran on after the tiles had drained (k_prepare 10.7 -> 13.7 us when every adaptive
     // frame got a plan), dispatched first they hide under the tiles.
     if (blockIdx.x == 0) {
+        // (the x-pair loads of the half-precision pyramid's last texel reach PYR16_PAD bytes past it: kept finite)
+        if (a.pyr16 && threadIdx.x < PYR16_PAD / 4) ((unsigned*)(a.pyr16 + (size_t)2 * a.pyrStride * a.B * a.V))[threadIdx.x] = 0u;
         for (int t = threadIdx.x; t < a.B * (a.V + 1); t += blockDim.x)
             if (t % (a.V + 1) == 0 || a.src_exts)
                 cam_prep_one(t, a.B, a.V, a.b, a.inv_depth, a.gnd, a.tar_exts, a.tar_ints, a.src_exts, a.src_ints, a.near_far, a.cams);
         return;
     }
     if ((int)blockIdx.x <= a.nplan) {
-        const int rowid = ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);
+        const int idx = ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);
+        zero_flat_counters(a, (int)blockIdx.x - 1, a.nplan);
         // (the plan rows borrow the tile's LDS: 128 words of bundle-start bits per row)
-        if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, (unsigned*)tile4 + (size_t)(threadIdx.x >> 6) * 128);
+        if (idx < a.B * a.plan_nr) plan_row(a, (idx / a.plan_nr) * a.H + a.plan_r0 + idx % a.plan_nr, threadIdx.x & 63, (unsigned*)tile4 + (size_t)(threadIdx.x >> 6) * 128);
         return;
     }
     const int blk = (int)blockIdx.x - 1 - a.nplan;
+    if (blk >= a.ntiles) { img16_block(a.src_images, a.img16, a.B * a.V, a.Ho, a.Wo, blk - a.ntiles); return; }
     const int tx = blk % a.tilesX, ty = (blk / a.tilesX) % a.tilesY, bv = blk / (a.tilesX * a.tilesY);
     const int x0 = tx * PT_W, y0 = ty * PT_H;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
@@ -501,16 +531,22 @@ int gdb_build_pyr16(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream
     hipLaunchKernelGGL(k_pyr16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)((char*)ws + L.pyrOff), (char*)ws + L.pyr16Off,
                        (unsigned)L.pyrStride, f->B * f->V, L.levels, f->H, f->W, (unsigned)L.lvlOff[1], (unsigned)L.lvlOff[2], (unsigned)L.lvlOff[3]);
     LAUNCH_CHECK("k_pyr16");
+    hipMemsetAsync((char*)ws + L.pyr16Off + (size_t)2 * L.pyrStride * f->B * f->V, 0, PYR16_PAD, st);
+    if (!f->d_src_images) return gdb_fail(GDB_E_BADARG, "a GDB_PREC_F16 render needs frame->d_src_images");
+    const size_t npair = (size_t)f->B * f->V * f->Ho * f->Wo / 2;
+    hipLaunchKernelGGL(k_img16, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, st, f->d_src_images, (char*)ws + L.img16Off, f->B * f->V, f->Ho, f->Wo);
+    LAUNCH_CHECK("k_img16");
     return GDB_OK;
 }
 
-static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_);
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_, int row_begin = 0, int row_end = -1);
 
 // The dense plan alone (for a render call that asks for GDB_SCHED_DENSE on a frame whose prepare did not build it).
 __global__ void __launch_bounds__(256) k_plan(PrepArgs a) {
     __shared__ unsigned words[4 * 128];
-    const int rowid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (rowid < a.B * a.H) plan_row(a, rowid, threadIdx.x & 63, words + (size_t)(threadIdx.x >> 6) * 128);
+    const int idx = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    zero_flat_counters(a, (int)blockIdx.x, (int)gridDim.x);
+    if (idx < a.B * a.plan_nr) plan_row(a, (idx / a.plan_nr) * a.H + a.plan_r0 + idx % a.plan_nr, threadIdx.x & 63, words + (size_t)(threadIdx.x >> 6) * 128);
 }
 int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream_t st) {
     WsLayout L = ws_layout(*cfg, *f);
@@ -519,6 +555,8 @@ int gdb_build_dense_plan(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipS
     a.near_far = f->d_near_far; a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
     a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff); a.nsamp = (int*)((char*)ws + L.nsampOff);
+    a.flat_cnt = (int*)((char*)ws + L.sideHdrOff); a.n_flat_cnt = L.flatMaxTiles + 1;
+    a.plan_r0 = 0; a.plan_nr = f->H;
     hipLaunchKernelGGL(k_plan, dim3((f->B * f->H + 3) / 4), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_plan");
     return GDB_OK;
@@ -535,13 +573,25 @@ extern "C" int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* f, const flo
     return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_);
 }
 
+// gdb_prepare_ex for a rank that renders ONE row strip of the frame: camera block and feature pyramid as ever (a strip's
+// samples project anywhere into the source views), the list schedules' plan for the bundle-map rows [row_begin, row_end) of every batch
+// item only.
+extern "C" int gdb_prepare_rows(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, int32_t flags, int32_t row_begin, int32_t row_end,
+                                void* ws, size_t ws_bytes, void* stream_) {
+    if (flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: unknown flag bits 0x%x", (unsigned)(flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)));
+    if ((flags & GDB_PREP_PYR16_ONLY) && !(flags & GDB_PREP_PYR16)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: GDB_PREP_PYR16_ONLY needs GDB_PREP_PYR16");
+    if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows with d_fpn_feat resamples frame->d_src_images: it is NULL");
+    if (row_end < 0) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) is negative", row_begin, row_end);
+    return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_, row_begin, row_end);
+}
+
 extern "C" int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, void* ws, size_t ws_bytes, void* stream_) {
     if (!d_fpn_feat) return gdb_fail(GDB_E_BADARG, "d_fpn_feat is NULL");
     if (!f || !f->d_src_images) return gdb_fail(GDB_E_BADARG, "gdb_prepare_fpn resamples frame->d_src_images: it is NULL");
     return prepare_common(cfg, f, d_fpn_feat, 0, ws, ws_bytes, stream_);
 }
 
-static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_) {
+static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_, int row_begin, int row_end) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, f, false); if (rc) return rc;
     if (!ws) return gdb_fail(GDB_E_BADARG, "workspace is NULL");
@@ -572,12 +622,19 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     a.S_max = cfg->max_num_samples; a.adaptive = cfg->is_adaptive; a.planL = L.planL; a.planMW = L.planMW;
     a.depth_range = f->d_depth_range; a.plan = (int*)((char*)ws + L.planOff);
     a.smap = (unsigned*)((char*)ws + L.smapOff); a.smapStride = L.smapStride; a.nwin = (int*)((char*)ws + L.nwinOff); a.nsamp = (int*)((char*)ws + L.nsampOff);
+    a.flat_cnt = (int*)((char*)ws + L.sideHdrOff); a.n_flat_cnt = L.flatMaxTiles + 1;
     // Built here (inside this launch, ~1 us) for adaptive configs (and the fixed-count ones the dense schedule takes:
     // gdb_fixed_counts_dense) whenever the frame carries its depth prior: a render call that
     // is told so (GDB_SCHED_PLAN_READY) uses it as it stands; any other dense render builds the plan itself (gdb_build_dense_plan,
     // a launch of its own on the same stream).
-    a.nplan = (f->d_depth_range && (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, f->V))) ? (f->B * f->H + 3) / 4 : 0;
-    hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan), dim3(256), 0, st, a);
+    if (row_end < 0) row_end = f->H;
+    if (row_begin < 0 || row_end > f->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, f->H);
+    a.plan_r0 = row_begin; a.plan_nr = row_end - row_begin;
+    a.nplan = (f->d_depth_range && a.plan_nr > 0 && (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, f->V))) ? (f->B * a.plan_nr + 3) / 4 : 0;
+    // the half-precision RGBA copy of the source images rides in the same launch, behind the pyramid tiles
+    a.img16 = (a.pyr16 && f->d_src_images && a.ntiles) ? (char*)ws + L.img16Off : nullptr;
+    a.nimg = a.img16 ? (int)(((size_t)f->B * f->V * f->Ho * f->Wo / 2 + 255) / 256) : 0;
+    hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan + a.nimg), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;
 }

@@ -93,6 +93,8 @@ class HotPathEngine:
         self._pyr16_ready = False
         self._pyr32_ready = True
         self._plan_static = False
+        self._plan_rows = (0, 0)
+        self._fused_ok = None
         self._fpn_ptr = None
         self.f16_only_prepare = True   # a PREC_F16 engine's prepare() writes the half-precision pyramid alone (see prepare)
         self.schedule = _lib.SCHED_AUTO
@@ -161,12 +163,14 @@ class HotPathEngine:
 
     # ---- per-frame preparation -----------------------------------------------------------
     @_on_device
-    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None) -> Optional[int]:
+    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None, rows=None) -> Optional[int]:
         """Validate shapes on the host, then build the camera block and the feature pyramid.  A frame
         without the source side (only tar_ext, tar_int, near_far [, depth_range, vol_range]; pass
         `im_size=(Ho,Wo)`) prepares the target camera alone — enough for build_rays / sample.
         Returns the number of mip levels built beyond level 0 (None without the source side); it is below
-        `max_mipmap_level` when an extent of the feature map turns odd on the way down (warned once)."""
+        `max_mipmap_level` when an extent of the feature map turns odd on the way down (warned once).
+        rows = (r0, r1): this engine will render the bundle-map rows [r0, r1) only (a rank's strip, `parallel.row_strip`): the list
+        schedules' plan is built for those rows alone (gdb_prepare_rows); a render outside them rebuilds the plan itself."""
         b = self.b
         if "src_images" in frame:
             si = frame["src_images"]
@@ -200,6 +204,7 @@ class HotPathEngine:
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         self._frame, self._keep = f, dict(frame)
+        self._fused_ok = None
         # gdb_prepare builds the dense schedule's plan from the depth prior as it is NOW (adaptive configs); a later render may
         # skip its own rebuild (GDB_SCHED_PLAN_READY) only while that tensor is unchanged: same storage, same version counter
         self._plan_key = None   # armed only once gdb_prepare has returned OK (below)
@@ -224,23 +229,48 @@ class HotPathEngine:
         flags = _lib.PREP_PYR16 if (self.precision == _lib.PREC_F16 and "src_images" in frame) else 0
         if flags and self.f16_only_prepare:
             flags |= _lib.PREP_PYR16_ONLY
-        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags,
-                                           self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        self._plan_rows = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+        if rows is None:
+            _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags,
+                                               self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        else:
+            _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
+                                                 self._ws.data_ptr(), self._ws.numel(), self._stream()))
         self._pyr16_ready = bool(flags & _lib.PREP_PYR16)
         self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
             self._plan_key = self._prior_key(frame.get("depth_range"))
-        self._plan_static = (not self.cfg.is_adaptive and (self.cfg.max_num_samples > 3 or self.cfg.max_num_samples == 2) and V <= 3 and "depth_range" in frame
-                             and "src_images" in frame)
+        # fixed counts: whether gdb_prepare built the list schedules' plan is the LIBRARY's rule (gdb_render_info out[2]), asked, not restated
+        self._plan_static = (not self.cfg.is_adaptive and "depth_range" in frame and "src_images" in frame
+                             and bool(self.render_info()["plan_built_by_prepare"]))
         return self.mip_levels
+
+    def render_info(self, precision: Optional[int] = None, row_begin: int = 0, row_end: Optional[int] = None) -> Dict[str, int]:
+        """What a fused render of the frame last prepared would do, as the library itself answers (gdb_render_info, ABI v6):
+        `fused` (0: only the operator mirrors run this config - bundle_size 1 / 4, a single view), `schedule` (what GDB_SCHED_AUTO
+        resolves to: 1 slot waves, 2 segment wave, 3 dense, 4 flat), `plan_built_by_prepare`, `launches`, `kernel` (its name in a trace)."""
+        f = self._need_frame()
+        out = (C.c_int32 * 4)()
+        precision = self.precision if precision is None else precision
+        _lib.check(self.lib.gdb_render_info(C.byref(self.cfg), C.byref(f), int(precision), int(row_begin), int(f.H if row_end is None else row_end), out))
+        sched = int(self.schedule) or int(out[1])
+        return {"fused": int(out[0]), "schedule": int(out[1]), "plan_built_by_prepare": int(out[2]), "launches": int(out[3]),
+                "kernel": {0: None, 1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[sched if out[0] else 0]}
+
+    @property
+    def fused_supported(self) -> bool:
+        """Whether gdb_render_bundles_fused / _packed accept this engine's config and the frame last prepared (asked once per prepare)."""
+        if self._fused_ok is None:
+            self._fused_ok = bool(self.render_info()["fused"])
+        return self._fused_ok
 
     def _need_pyr32(self) -> None:
         """The fp32 feature pyramid of the frame last prepared, built now if that prepare wrote the half-precision copy alone."""
         if getattr(self, "_pyr32_ready", True) or self._frame is None:
             return
         flags = _lib.PREP_PYR16 if self._pyr16_ready else 0
-        _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(self._frame), self._fpn_ptr, flags,
-                                           self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(self._frame), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
+                                             self._ws.data_ptr(), self._ws.numel(), self._stream()))
         self._pyr32_ready = True
 
     @staticmethod
@@ -255,7 +285,7 @@ class HotPathEngine:
             if dr.is_inference():
                 return None
             return (dr.data_ptr(), dr._version)
-        except RuntimeError:
+        except (RuntimeError, AttributeError):   # (`_version` is a private attribute: a torch without it degrades to "rebuild the plan")
             return None
 
     def invalidate_plan(self) -> None:
@@ -425,12 +455,14 @@ class HotPathEngine:
             raise ValueError("Rays have not been built yet. Please call prepare() first.")
         return self._frame
 
-    def _sched(self) -> int:
+    def _sched(self, row_begin: int = 0, row_end: Optional[int] = None) -> int:
         """The schedule argument of a render call: this engine's schedule, plus the plan-is-current flag while the depth prior
-        the last prepare() consumed is untouched."""
+        the last prepare() consumed is untouched and the strip lies inside the rows that prepare planned."""
         ready = self._plan_key is not None and self._prior_key(self._keep.get("depth_range")) == self._plan_key
         if not self.cfg.is_adaptive:   # fixed counts: the plan gdb_prepare built (gdb_fixed_counts_dense) does not depend on the prior's values
             ready = self._plan_static
+        p0, p1 = self._plan_rows
+        ready = ready and row_begin >= p0 and (self._frame.H if row_end is None else row_end) <= p1
         return int(self.schedule) | (_lib.SCHED_PLAN_READY if ready else 0) | (_lib.SCHED_PYR16_READY if self._pyr16_ready else 0)
 
     @property
@@ -547,6 +579,19 @@ class HotPathEngine:
         _, bf, depth, opac = self.composite(sigma, feat, s["z_vals"], s["indices"], self.n_bundles, s["total"])
         return bf, depth, opac
 
+    def render_unfused_packed(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The operator-mirror chain into the packed (n_bundles, Q + 2) rows [bundle_feat | depth | opacity] `render_packed` returns:
+        what `Network.forward` takes when the fused entries refuse the config (bundle_size 1 / 4; `fused_supported`)."""
+        bf, depth, opac = self.render_unfused()
+        nb = self.n_bundles
+        if out is None:
+            out = self._buf("render.packed", (nb, self.Q + 2), internal=True)
+        _chk(out, "out", (nb, self.Q + 2))
+        out[:, :self.Q] = bf
+        out[:, self.Q] = depth
+        out[:, self.Q + 1] = opac
+        return out
+
     # ---- production entry ----------------------------------------------------------------
     @_on_device
     def render(self, row_begin: int = 0, row_end: Optional[int] = None, precision: Optional[int] = None, out=None):
@@ -570,7 +615,7 @@ class HotPathEngine:
         bf, depth, opac = out
         _chk(bf, "bundle_feat", (nb, self.Q)); _chk(depth, "depth", (nb,)); _chk(opac, "opacity", (nb,))
         _lib.check(self.lib.gdb_render_bundles_fused(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
-                                                     int(row_begin), int(row_end), int(precision), self._sched(), bf.data_ptr(),
+                                                     int(row_begin), int(row_end), int(precision), self._sched(row_begin, row_end), bf.data_ptr(),
                                                      depth.data_ptr(), opac.data_ptr(), self._stream()))
         return bf, depth, opac
 
@@ -593,6 +638,6 @@ class HotPathEngine:
             out = self._buf("render.packed", (nb, self.Q + 2), internal=True) if full else torch.zeros((nb, self.Q + 2), device=self.device)
         _chk(out, "out", (nb, self.Q + 2))
         _lib.check(self.lib.gdb_render_bundles_packed(C.byref(self.cfg), C.byref(f), self._ws.data_ptr(), self.weights.data_ptr(),
-                                                      int(row_begin), int(row_end), int(precision), self._sched(),
+                                                      int(row_begin), int(row_end), int(precision), self._sched(row_begin, row_end),
                                                       out.data_ptr(), self._stream()))
         return out

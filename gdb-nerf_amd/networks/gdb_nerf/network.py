@@ -115,6 +115,11 @@ class Network(nn.Module):
         """The hot path of the prepared frame into packed rows [bundle_feat | depth | opacity] (n_bundles, Q + 2); row-sharded over
         the ranks of the default process group when `nerf.shard: rows` (reference call site network.py:145-169; the eval loop
         run.py:54-66 calls this once per frame on every rank)."""
+        if not eng.fused_supported:
+            # bundle_size 1 / 4 (configs/dtu_pretrain.yaml:33 "4 for 4*4"; network.py:31-34 accepts any power of two): the fused kernel
+            # is built for b = 2, so the frame goes through the HIP operator mirrors (gdb_sample -> gdb_encode -> gdb_mlp ->
+            # gdb_composite), whole on every rank (the mirrors take no row strip).
+            return eng.render_unfused_packed()
         dist = self._dist()
         if dist is None:
             return eng.render_packed()
@@ -182,10 +187,17 @@ class Network(nn.Module):
         if self.hot_path == "fused":
             c = lambda t: t.contiguous().float()
             eng = self._get_engine(src_images.device)
+            # a rank of a row-sharded forward plans its own strip of bundle-map rows only (the pyramid stays whole: a strip's samples
+            # project anywhere into the source views)
+            dist = self._dist()
+            rows = None
+            if dist is not None and self.b_size == 2:
+                from ...parallel import row_strip
+                rows = row_strip(H, dist.get_rank(), dist.get_world_size())
             # N3: the kernel resamples the colour channels itself (no torch.cat / F.interpolate of the source images)
             eng.prepare({"src_images": c(src_images), "fpn_feat": c(img_feat), "feat_volume": c(feat_volume),
                          "depth_range": c(depth_range), "vol_range": c(vol_range), "src_exts": c(src_exts), "src_ints": c(src_ints),
-                         "tar_ext": c(tar_exts), "tar_int": c(tar_ints), "near_far": c(near_far)})
+                         "tar_ext": c(tar_exts), "tar_int": c(tar_ints), "near_far": c(near_far)}, rows=rows)
             packed = self._render_packed(eng, B, H, W)
             if self.hip_decoder:
                 rgb_c = eng.decode(packed)   # reads channels 3 b^2 .. Q-1 of the packed rows in place

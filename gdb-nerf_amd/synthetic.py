@@ -49,7 +49,7 @@ def look_at_w2c(cam: np.ndarray, target: np.ndarray) -> np.ndarray:
 
 def make_frame(Ho: int, Wo: int, V: int = 3, B: int = 1, *, bundle_size: int = 2, feat_dim: int = 16,
                voxel_dim: int = 8, num_depth: int = 8, scene: str = "dtu", seed: int = 0,
-               smooth_feat: int = 0, src_focal_scale=None) -> dict:
+               smooth_feat: int = 0, smooth_vol: int = 0, src_focal_scale=None) -> dict:
     """One batch of hot-path inputs, all float32 numpy arrays (layouts as the reference's)."""
     near, far, look, radius = SCENES[scene]
     rng = np.random.default_rng(seed)
@@ -80,6 +80,8 @@ def make_frame(Ho: int, Wo: int, V: int = 3, B: int = 1, *, bundle_size: int = 2
     rgb_lo = src_images.reshape(B, V, 3, H, b, W, b).mean(axis=(4, 6), dtype=F32)
     img_feat = np.concatenate((feat, rgb_lo), axis=2).astype(F32)
     feat_volume = rng.standard_normal((B, voxel_dim, num_depth, H, W), dtype=F32)
+    if smooth_vol:  # a cost volume without per-voxel white noise (the regularised volume of a trained net is smooth in x, y)
+        feat_volume = (_box(feat_volume, smooth_vol) * F32(smooth_vol)).astype(F32)
 
     mid = _box((near + 0.2 * R + 0.6 * R * rng.random((B, 1, H, W), dtype=F32)).astype(F32), 9)
     half = ((0.2 + 1.8 * rng.random((B, 1, H, W), dtype=F32)) * F32(R / 64)).astype(F32)

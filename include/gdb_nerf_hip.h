@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 5
+#define GDB_ABI_VERSION 6
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -159,6 +159,13 @@ int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_
 int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, void* d_workspace,
                    size_t workspace_bytes, void* stream);
 
+/* gdb_prepare_ex for a rank that renders ONE row strip of the frame (multi-GPU row sharding; ABI v6): camera block and
+ * feature pyramid as ever (a strip's samples project anywhere into the source views), the list schedules' plan for the bundle-map
+ * rows [row_begin, row_end) of every batch item only - the rows outside the strip are another rank's.  GDB_SCHED_PLAN_READY then
+ * holds for render calls whose strip lies inside [row_begin, row_end). */
+int gdb_prepare_rows(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, int32_t row_begin,
+                     int32_t row_end, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Where the half-precision pyramid sits in the workspace (tests / callers that read it): out[0] = byte offset, out[1] = bytes per
  * (batch, view), out[2] = mip levels beyond 0, out[3 + l] = byte offset of level l inside a (batch, view) block.  A level of hw
  * texels is three planes: [0, 16 hw) 16 bytes per texel = halves of channels 0..3, 8..11; [16 hw, 32 hw) channels 4..7, 12..15;
@@ -248,8 +255,10 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   (bundle_sampler.py:182-189): one wave per window of WHOLE consecutive bundles of a bundle-map row holding <= 32 samples,
  *   composite across lanes; GDB_SCHED_FLAT = the same list read as one list over the rows and cut into windows of EXACTLY 32
  *   consecutive samples (4-8 % fewer waves; a bundle may straddle two windows - both waves then leave its samples' records in
- *   d_workspace and a small second launch composites it with the in-wave composite's own arithmetic, bit for bit: the result
- *   does not depend on where the windows fall, row strips equal the full render; bit-identical to GDB_SCHED_DENSE).
+ *   d_workspace and whichever of the two arrives last at the boundary's counter composites it, inside the same launch, with the in-wave
+ *   composite's own arithmetic, bit for bit: the result depends neither on where the windows fall nor on the order of arrival, row strips
+ *   equal the full render; bit-identical to GDB_SCHED_DENSE.  The counters live in d_workspace, are zeroed by gdb_prepare and by the
+ *   plan rebuild of a render call, and are left at zero by every completed render: one render at a time per workspace).
  *   (GDB_SCHED_AUTO takes DENSE for adaptive counts, FLAT where it measured faster: fp32, S_max <= 4, frames of few tiles per
  *   wave slot.  Both need the per-row plan + sample list in d_workspace: by default the render
  *   call builds them itself from frame->d_depth_range, a small launch of its own on the same stream — the one place a render
@@ -275,6 +284,16 @@ int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const 
                              const float* d_packed_weights, int32_t row_begin, int32_t row_end,
                              int32_t precision, int32_t schedule, float* d_bundle_feat, float* d_depth,
                              float* d_opacity, void* stream);
+
+/* What the two fused entries would do for this (config, frame shape, precision, row strip), without launching anything (ABI v6): the
+ * library's own answer, so that no caller restates its rules.  shape needs B, V, Ho, Wo, H, W, D (no pointers).
+ *   out[0]  1 when gdb_render_bundles_fused / _packed accept the config and frame (bundle_size 2, >= 2 source views); 0: only the operator
+ *           mirrors above run it (gdb_sample -> gdb_encode -> gdb_mlp -> gdb_composite; bundle_size 1 and 4).
+ *   out[1]  the schedule GDB_SCHED_AUTO resolves to for this call (GDB_SCHED_SLOT_WAVES .. GDB_SCHED_FLAT; 0 when out[0] is 0).
+ *   out[2]  1 when gdb_prepare builds the list schedules' plan for this config if the frame it is given carries d_depth_range - i.e. when a
+ *           render of that frame may be passed GDB_SCHED_PLAN_READY (adaptive counts: while the contents of d_depth_range are unchanged).
+ *   out[3]  kernel launches the render enqueues (1; one per batch item for the flat schedule and for a dense row strip of a batch). */
+int gdb_render_info(const GdbConfig* cfg, const GdbFrame* shape, int32_t precision, int32_t row_begin, int32_t row_end, int32_t out[4]);
 
 /* The same with ONE output buffer d_out (B*H*W, Q+2), row = [bundle_feat (Q) | depth | opacity]: what
  * Network.render_bundles returns (network.py:54-91) as a single tensor, so that a row strip is one contiguous

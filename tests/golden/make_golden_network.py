@@ -102,5 +102,49 @@ def more(net7, RefNetwork):
               "S_max", net.max_num_samples, "render_scale", scale)
 
 
+# The 4x4 configuration the reference's YAML comments describe (configs/dtu_pretrain.yaml:23-24,33: bundle_size 4, vol_levels [0, 0],
+# vol_scales [0.125, 0.25]) with the pyramid level the bundle map then reads (feat_level 0, network.py:40-43) carrying 16 channels,
+# the feature width this build's kernels are specialised for.
+B4_OPTS = ["nerf.bundle_size", "4", "mvs.vol_levels", "[0, 0]", "mvs.vol_scales", "[0.125, 0.25]", "fpn.feat_dims", "[16, 16, 8]"]
+
+
+def bundle4(RefNetwork):
+    """F7d - `configs/dtu_eval.yaml` with bundle_size 4 (network.py:31-34 accepts any power of two): its own checkpoint (the decoder
+    has two up stages, decoder_rdn.py:52-63), the reference's forward on a 64x96 frame."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    torch.manual_seed(4)
+    net = RefNetwork(make_cfg("configs/dtu_eval.yaml", B4_OPTS)).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p.half().float())
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.8, 1.2)
+                m.running_mean.copy_(m.running_mean.half().float())
+                m.running_var.copy_(m.running_var.half().float())
+    frame = synthetic.make_frame(64, 96, V=3, B=1, seed=14)
+    frame["src_images"] = frame["src_images"].astype(np.float16).astype(np.float32)
+    batch = {"src_views": {"rgb": t(frame["src_images"]), "extrinsics": t(frame["src_exts"]), "intrinsics": t(frame["src_ints"])},
+             "tar_views": {"extrinsics": t(frame["tar_ext"]), "intrinsics": t(frame["tar_int"])}, "near_far": t(frame["near_far"])}
+    with torch.no_grad():
+        ret, mvs_depths, blend = net(batch)
+    sd = {("sd." + k): (v.numpy().astype(np.float16) if v.dtype == torch.float32 else v.numpy()) for k, v in net.state_dict().items()}
+    out = dict(src_images=frame["src_images"].astype(np.float16), src_exts=frame["src_exts"], src_ints=frame["src_ints"],
+               tar_ext=frame["tar_ext"], tar_int=frame["tar_int"], near_far=frame["near_far"],
+               rgb=ret["rgb"].numpy(), nerf_depth=ret["nerf_depth"].numpy(), mvs_depth=ret["mvs_depth"].numpy(), opacity=ret["opacity"].numpy(),
+               opts=np.array(B4_OPTS), **sd)
+    path = os.path.join(HERE, "F7d_network_bundle4.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; rgb", tuple(ret["rgb"].shape), "bundle_size", net.b_size, "feat_level", net.feat_level)
+
+
 if __name__ == "__main__":
-    main()
+    if "--bundle4" in sys.argv:   # F7d alone (F7 .. F7c are regenerated bit for bit by the default run)
+        mg._placeholders()
+        from networks.gdb_nerf.network import Network as RefNetwork
+        bundle4(RefNetwork)
+    else:
+        main()
+        from networks.gdb_nerf.network import Network as RefNetwork
+        bundle4(RefNetwork)

@@ -50,7 +50,9 @@ def test_workspace_bytes_and_errors(lib):
     # sample list (4 B per sample offset of a row)
     # ... and the flat schedule's straddling-bundle records: (81920 x 3 / 32 + 3) boundaries x 3 samples x 2 lane halves x 24 floats, + headers
     flat = (256 * 320 * 3 // 32 + 3) * (3 * 2 * 24 * 4 + 8)
-    assert pyr + pyr // 2 < n.value < pyr + pyr // 2 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + flat + 96 * 1024
+    # ... and the half-precision RGBA copy of the source images (GDB_PREC_F16's colour taps): 8 bytes per pixel and view
+    img16 = 3 * 512 * 640 * 8
+    assert pyr + pyr // 2 + img16 < n.value < pyr + pyr // 2 + img16 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + flat + 96 * 1024
     # reference error: network.py:33-34 ValueError('`Bundle size` must be a power of 2.')
     with pytest.raises(ValueError, match="power of 2"):
         _lib.check(lib.gdb_workspace_bytes(C.byref(_cfg(bundle_size=3)), C.byref(_shape()), C.byref(n)))
@@ -129,7 +131,7 @@ int main(void) {
     GdbConfig c; GdbFrame f;
     if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
     for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
-    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 5) return 12;
+    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 6) return 12;
     memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
     c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
     if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */

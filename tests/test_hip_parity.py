@@ -8,8 +8,10 @@ Tolerances (float32, absolute unless stated):
     of difference is summation order and the 1-ulp freedom of the camera inverses, amplified
     by white-noise feature gradients);
   * fused kernel, GDB_PREC_F16 (f16 MFMA operands): 2e-3 abs on bundle_feat, PSNR delta <= 0.05 dB (north_star);
-  * fused kernel, GDB_PREC_F32 (fp32 MFMA, the reference's precision): 5e-4 abs (fp32 coordinate noise on white-noise
-    features, see FUSED_TOL_F32), PSNR delta <= 0.05 dB.
+  * fused kernel, GDB_PREC_F32 / F32X (fp32 MFMA, the reference's precision; split-f16 pairs): 3 x the largest error observed on
+    MI355X per frame class (profiles/r05/parity_observed.txt) - 5e-5 on the fixture-size frames, 3e-4 at c2, 5e-4 on the larger
+    frames (fp32 coordinate noise on white-noise features: FUSED_TOL_F32) and 2e-5 on the smooth-feature c2 frame, where that noise
+    is out of the way and the bound sees the arithmetic; PSNR delta <= 0.05 dB.
 """
 import numpy as np
 import pytest
@@ -42,8 +44,11 @@ def mode(request):
     return request.param
 
 
-def fused_tol(mode):
-    return FUSED_TOL if mode[1] == 0 else FUSED_TOL_F32
+def fused_tol(mode, size="small"):
+    """size: "small" = the fixture-size frames (<= 128 px), "c2" = 512x640, "large" = c3 .. c5."""
+    if mode[1] == 0:
+        return FUSED_TOL
+    return {"small": FUSED_TOL_F32_SMALL, "c2": FUSED_TOL_F32_C2, "large": FUSED_TOL_F32}[size]
 
 
 def engine_for(frame, weights=None, mode=None, **cfg):
@@ -285,6 +290,15 @@ FUSED_TOL = 2e-3      # GDB_PREC_F16: abs, on O(1) bundle features; observed ~2e
 # GDB_PREC_F32X (split-f16 operand pairs, ~22 bits) is held to the same bound: its MLP differs from the fp32 one by ~1e-6
 # (test_split_f16_precision_tracks_fp32 bounds that difference directly), far below the coordinate effect.
 FUSED_TOL_F32 = 5e-4
+# Per frame class, 3 x the largest error observed on MI355X (profiles/r05/parity_observed.txt; VERDICT r04 weak 1: one bound of
+# 5e-4 everywhere let a 1e-4 arithmetic slip pass every small-frame test).  Fixture-size frames (<= 128 px: F6, c1, the corner and
+# degenerate cases): fp32 / split-f16 1.4e-5 at most (48x80 V2 S3; 7e-6 typical) -> 5e-5; the fp32 operator chain 1.1e-5 -> 4e-5.
+# c2 (512x640): 9.7e-5 against the oracle, 9.5e-5 against the fp32 chain -> 3e-4.  c3 / c3' / c4 / c5: 1.8e-4 .. 2.5e-4 -> the 5e-4
+# above (2 x).  GDB_PREC_F16 keeps 2e-3: 1.07e-3 at most on the small frames, 7.9e-4 at c2, 1.03e-3 at c3.
+FUSED_TOL_F32_SMALL = 5e-5
+FUSED_TOL_F32_C2 = 3e-4
+CHAIN_TOL_SMALL = 4e-5   # the exact-fp32 operator chain on the fixture-size frames
+SMOOTH_C2_TOL_F32 = 2e-5  # c2-size frame with CNN-generated features and a smooth volume: coordinate noise out of the way
 F32X_VS_F32_TOL = 2e-5
 
 
@@ -354,7 +368,7 @@ def test_fused_config_corners(Ho, Wo, V, S, adaptive, extra, mode):
     ubf, ud, uo = eng.render_unfused()
     e, eu = max_abs(npy(bf), obf), max_abs(npy(ubf), obf)
     print(f"corner {Ho}x{Wo} V{V} S{S} {extra}: fused err {e:.3e}, fp32 chain err {eu:.3e}")
-    assert eu <= 2e-4
+    assert eu <= CHAIN_TOL_SMALL
     assert e <= fused_tol(mode)
     assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max())
     assert max_abs(npy(opac), oo) <= 1e-5
@@ -393,7 +407,7 @@ def test_fused_degenerate_geometry(kind, mode):
     e, eu = max_abs(npy(bf), obf), max_abs(npy(ubf), obf)
     print(f"degenerate {kind}: fused err {e:.3e}, fp32 chain err {eu:.3e}")
     assert np.isfinite(npy(bf)).all() and np.isfinite(npy(ubf)).all()
-    assert eu <= 2e-4
+    assert eu <= CHAIN_TOL_SMALL
     assert e <= fused_tol(mode)
     assert max_abs(npy(opac), oo) <= 1e-5
 
@@ -409,7 +423,7 @@ def test_fused_matches_unfused_at_full_size(mode):
     ubf, ud, uo = eng.render_unfused()
     e = max_abs(npy(bf), npy(ubf))
     print(f"fused vs fp32 chain at 512x640: max abs err {e:.3e}")
-    assert e <= fused_tol(mode)
+    assert e <= fused_tol(mode, "c2")
     assert max_abs(npy(depth), npy(ud)) <= 2e-3 * 905.0
     # normalised weights sum to one; depth stays inside the prior
     assert float((opac - 1).abs().max()) <= 1e-5
@@ -435,7 +449,7 @@ def test_c2_full_size_against_the_oracle():
     print(f"c2 512x640 vs oracle: fp32 operator chain max abs err {eu:.3e}")
     assert eu <= 2e-4 and max_abs(npy(ud), od) <= 1e-4 * float(np.abs(od).max()) and max_abs(npy(uo), oo) <= 1e-5
     for sched in (1, 2, 3, 4):
-        for prec, tol in ((1, FUSED_TOL_F32), (2, FUSED_TOL_F32), (0, FUSED_TOL)):
+        for prec, tol in ((1, FUSED_TOL_F32_C2), (2, FUSED_TOL_F32_C2), (0, FUSED_TOL)):
             eng.set_schedule(sched)
             bf, depth, opac = eng.render(precision=prec)
             e = max_abs(npy(bf), obf)
@@ -468,6 +482,66 @@ def test_c3_c4_full_size_against_the_oracle(name, Ho, Wo, S, scene, seed):
     assert eu <= 2e-4 and max_abs(npy(ud), od) <= 1e-4 * float(np.abs(od).max()) and max_abs(npy(uo), oo) <= 1e-5
     assert e <= FUSED_TOL_F32 and dpsnr <= 0.05
     assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max()) and max_abs(npy(opac), oo) <= 1e-5
+
+
+def _smooth_c2_frame():
+    """A c2-size frame whose gathered tensors are smooth, as a trained network's are: `img_feat` is the package's FeatureNet (the
+    weights of fixture F7: the reference's own random-init FPN, feature_net.py:40-64) run on the synthetic source images (level 1, 16
+    channels) + the downsampled colours (network.py:159-164), and the cost volume is box-filtered noise.  On white-noise features the
+    gradient is O(1) per texel and 1e-4 px of fp32 coordinate noise sets the error floor (FUSED_TOL_F32_C2); here the floor is the
+    arithmetic's own."""
+    from gdb_nerf_amd.networks.gdb_nerf.feature_net import FeatureNet
+    fx = load_golden("F7_network")
+    frame = synthetic.make_frame(512, 640, V=3, seed=0, smooth_vol=5)
+    net = FeatureNet(base_channels=8, out_channels=[32, 16, 8]).eval()
+    sd = {k[len("sd.feature_net."):]: (torch.from_numpy(np.asarray(v)).float() if v.dtype == np.float16 else torch.from_numpy(np.asarray(v)))
+          for k, v in fx.items() if k.startswith("sd.feature_net.")}
+    net.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        feat = 8.0 * net(torch.from_numpy(frame["src_images"][0]))[1].numpy()    # (V, 16, 256, 320); x 8: unit-scale values (std 0.8), still smooth
+    frame["img_feat"] = np.concatenate((feat[None], frame["img_feat"][:, :, 16:]), axis=2).astype(np.float32)
+    return frame
+
+
+def test_smooth_feature_c2_frame_against_the_oracle():
+    """at c2's size on CNN-generated features the fp32 kernels are held to 2e-5 against the oracle (observed
+    printed), under every schedule - a bound that sees a wrong rounding or a dropped bias term in one MLP layer, which the
+    white-noise frames' 1e-4 of coordinate noise would hide.  Reference: nerf.py:100-113, bundle_sampler.py:327-359."""
+    frame = _smooth_c2_frame()
+    w = synthetic.make_nerf_weights(seed=0)
+    with np.errstate(all="ignore"):
+        obf, od, oo = oracle.hot_path(frame, w, max_num_samples=3, is_adaptive=True)
+    eng = engine_for(frame, w, max_num_samples=3, is_adaptive=True)
+    eu = max_abs(npy(eng.render_unfused()[0]), obf)
+    print(f"smooth c2 frame vs oracle: fp32 operator chain max abs err {eu:.3e}")
+    assert eu <= SMOOTH_C2_TOL_F32
+    for sched in (1, 2, 3, 4):
+        eng.set_schedule(sched)
+        for prec, tol in ((1, SMOOTH_C2_TOL_F32), (2, SMOOTH_C2_TOL_F32), (0, FUSED_TOL)):
+            bf, depth, opac = eng.render(precision=prec)
+            e = max_abs(npy(bf), obf)
+            print(f"smooth c2 frame vs oracle: fused schedule {sched} precision {prec}: max abs err {e:.3e}, rms {np.sqrt(np.mean((npy(bf) - obf) ** 2)):.3e}")
+            assert e <= tol
+            assert max_abs(npy(depth), od) <= 2e-3 * float(np.abs(od).max()) and max_abs(npy(opac), oo) <= 1e-5
+
+
+@pytest.mark.parametrize("prec", [1, 2], ids=["f32", "f32x"])
+def test_the_bounds_see_a_1e4_bias_slip(prec):
+    """The tolerances must be tight enough to catch an arithmetic slip of 1e-4 in one MLP layer: with
+    lr0.0.bias (nerf.py:100) moved by +1e-4 in the weights the DEVICE gets - every packed section, the fp32-MFMA bias table T32_LR0
+    included - and the oracle left on the true weights, the fused render must EXCEED the bound its frame class is held to, on the
+    c1-size frame and on the smooth c2 frame (and the same render on the true weights must stay inside it)."""
+    w = synthetic.make_nerf_weights(seed=5)
+    w_bad = dict(w)
+    w_bad["lr0.0.bias"] = (w["lr0.0.bias"] + np.float32(1e-4)).astype(np.float32)
+    for name, frame, tol in (("c1 64x80", synthetic.make_frame(64, 80, V=3, seed=21), FUSED_TOL_F32_SMALL),
+                             ("smooth c2", _smooth_c2_frame(), SMOOTH_C2_TOL_F32)):
+        with np.errstate(all="ignore"):
+            obf = oracle.hot_path(frame, w, max_num_samples=3, is_adaptive=True)[0]
+        good = max_abs(npy(engine_for(frame, w, (0, prec), max_num_samples=3, is_adaptive=True).render()[0]), obf)
+        bad = max_abs(npy(engine_for(frame, w_bad, (0, prec), max_num_samples=3, is_adaptive=True).render()[0]), obf)
+        print(f"{name}, precision {prec}: err on the true weights {good:.3e}, with lr0.0.bias + 1e-4 {bad:.3e} (bound {tol:.0e})")
+        assert good <= tol < bad
 
 
 def test_hot_path_section_allocates_nothing_per_frame():
@@ -508,7 +582,7 @@ def test_fused_is_deterministic_at_full_size(mode):
     ubf = eng.render_unfused()[0]
     for _ in range(6):
         assert torch.equal(eng.render()[0], ref)
-    assert max_abs(npy(ref), npy(ubf)) <= fused_tol(mode)
+    assert max_abs(npy(ref), npy(ubf)) <= fused_tol(mode, "c2")
 
 
 def test_fused_row_strips_tile_the_frame(mode):
@@ -547,6 +621,7 @@ def test_fused_schedules_agree_and_reject_bad_mode(prec):
     eng.set_schedule(1); a = [t.clone() for t in eng.render()]
     for other in (2, 3, 4):
         eng.set_schedule(other); b = [t.clone() for t in eng.render()]
+        print(f"precision {prec}: schedule 1 vs {other}: max abs diff {max_abs(npy(a[0]), npy(b[0])):.3e}")
         assert max_abs(npy(a[0]), npy(b[0])) <= 2e-6
         assert max_abs(npy(a[1]), npy(b[1])) <= 2e-6 * float(a[1].abs().max())
         assert max_abs(npy(a[2]), npy(b[2])) <= 2e-6
@@ -773,7 +848,9 @@ def test_fused_random_shapes_vs_fp32_chain(case, mode):
     bf, depth, opac = [t.clone() for t in eng.render()]
     ubf, ud, uo = eng.render_unfused()
     assert np.isfinite(npy(bf)).all()
-    assert max_abs(npy(bf), npy(ubf)) <= fused_tol(mode)
+    e = max_abs(npy(bf), npy(ubf))
+    print(f"random shape {c['Ho']}x{c['Wo']} V{c['V']} B{c['B']} S{c['S']}: fused vs fp32 chain max abs err {e:.3e}")
+    assert e <= fused_tol(mode, "c2" if max(c["Ho"], c["Wo"]) > 128 else "small")
     assert max_abs(npy(opac), npy(uo)) <= 1e-5
     # disparity sampling returns 1/(sum w/z): compare where the reference value is finite
     fin = np.isfinite(npy(ud))
@@ -856,7 +933,7 @@ def test_fused_matches_fp32_chain_at_baseline_sizes(name, Ho, Wo, V, S, adaptive
     ubf, ud, uo = eng.render_unfused()
     e = max_abs(npy(bf), npy(ubf))
     print(f"{name} {Ho}x{Wo} V{V} S{S}: fused vs fp32 chain max abs err {e:.3e}")
-    assert e <= fused_tol(mode)
+    assert e <= fused_tol(mode, "large")
     assert max_abs(npy(opac), npy(uo)) <= 1e-5
     assert max_abs(npy(depth), npy(ud)) <= 2e-3 * float(ud.abs().max())
     assert float((opac - 1).abs().max()) <= 1e-5            # every bundle has samples: normalised weights sum to one

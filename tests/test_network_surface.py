@@ -187,6 +187,45 @@ def test_network_forward_matches_reference_on_the_other_branches(f7, fixture, ho
     assert d_psnr <= 0.05
 
 
+def test_bundle_size_4_network_loads_the_reference_checkpoint():
+    """configs/dtu_pretrain.yaml:33 "bundle_size: 2  # 4 for 4*4": the 4x4 configuration (vol_levels [0, 0], vol_scales [0.125, 0.25])
+    builds with the reference's checkpoint layout - a decoder with two up stages (decoder_rdn.py:52-63) - and keeps the PyTorch
+    decoder (the HIP decoder is built for one up stage).  Fixture F7d: the reference's own Network under that configuration."""
+    fx = load_golden("F7d_network_bundle4")
+    net = make_network(make_cfg("configs/dtu_eval.yaml", [str(x) for x in fx["opts"]])).eval()
+    missing = net.load_state_dict(_state_dict(fx), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert net.b_size == 4 and net.feat_level == 0 and net.hip_decoder is False and net.hot_path == "fused"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hot_path", ["fused", "mirrors"])
+def test_network_forward_bundle_size_4_matches_reference(hot_path):
+    """a bundle_size 4 config goes through Network.forward on the HIP library - the fused entries refuse b != 2
+    (gdb_render_info out[0] = 0), so the default hot path dispatches to the HIP operator-mirror chain (gdb_sample -> gdb_encode ->
+    gdb_mlp -> gdb_composite) by itself instead of raising; merge runs on the HIP kernel (k_merge<4>), the two-stage decoder on
+    PyTorch-ROCm.  Against the reference's own forward (F7d; network.py:31-34, 145-182)."""
+    fx = load_golden("F7d_network_bundle4")
+    net = make_network(make_cfg("configs/dtu_eval.yaml", [str(x) for x in fx["opts"]] + ["nerf.hot_path", hot_path])).eval()
+    net.load_state_dict(_state_dict(fx), strict=True)
+    net = net.cuda()
+    fxb = dict(fx); fxb["src_images"] = fx["src_images"].astype(np.float32)
+    with torch.no_grad():
+        ret, mvs_depths, blend = net(_batch(fxb, "cuda"))
+    if hot_path == "fused":
+        assert net._engine is not None and net._engine.fused_supported is False   # the dispatch, not an exception
+    assert tuple(ret["rgb"].shape) == tuple(fx["rgb"].shape) == (1, 3, 64, 96)
+    e = max_abs(ret["rgb"].cpu().numpy(), fx["rgb"])
+    print(f"F7d bundle_size 4 ({hot_path}): max |rgb - reference| = {e:.3e}")
+    assert e <= 5e-4
+    assert max_abs(ret["mvs_depth"].cpu().numpy(), fx["mvs_depth"]) <= 1e-3 * float(np.abs(fx["mvs_depth"]).max())
+    assert max_abs(ret["nerf_depth"].cpu().numpy(), fx["nerf_depth"]) <= 2e-3 * float(np.abs(fx["nerf_depth"]).max())
+    assert max_abs(ret["opacity"].cpu().numpy(), fx["opacity"]) <= 1e-4
+    gt = np.clip(np.transpose(fx["rgb"][0], (1, 2, 0)) + np.random.default_rng(1).normal(0, 0.03, (64, 96, 3)), 0, 1)
+    d_psnr = abs(oracle.psnr(gt, np.transpose(ret["rgb"][0].cpu().numpy(), (1, 2, 0))) - oracle.psnr(gt, np.transpose(fx["rgb"][0], (1, 2, 0))))
+    assert d_psnr <= 0.05
+
+
 @pytest.mark.gpu
 def test_forward_under_inference_mode_and_outputs_outlive_the_next_frame(f7):
     """(1) tensors created under torch.inference_mode() have no version counter - the engine's plan key read

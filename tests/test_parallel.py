@@ -115,6 +115,7 @@ class _FakeHotPath:
     def __init__(self, truth, B, H):
         self.truth, self.B, self.H, self.Q, self.device = truth, B, H, truth.shape[1] - 2, torch.device("cpu")
         self.calls = []
+        self.fused_supported = True   # (bundle_size 2: what HotPathEngine answers from gdb_render_info)
 
     def render_packed(self, r0=0, r1=None, precision=None, out=None):
         r1 = self.H if r1 is None else r1
@@ -247,6 +248,10 @@ def test_bench_self_launches_its_ranks():
     assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
     assert rec["plumbing_only"] is True and rec["gathered_equals_full_render"] is True
     assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1]
+    # the N > 1 headline is north_star's partitioning: one frame, row strips, ONE all-gather (strong scaling); the line says so
+    assert rec["scaling"] == "strong" and rec["config"]["shard"] == "rows" and rec["mode"].startswith("rows:") and "gloo" in rec["collective"]
+    assert all(set(r) >= {"rank", "rows", "prepare_ms", "kernel_ms", "allgather_ms", "bus_GBps"} for r in rec["per_rank"])
+    assert sorted(tuple(r["rows"]) for r in rec["per_rank"]) == [(0, 16), (16, 32)]
     # a failing rank is not swallowed: the launcher's exit code comes back
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env={k: v for k, v in env.items() if k != "GDB_BENCH_REHEARSE"}, capture_output=True, text=True, timeout=300)
@@ -257,32 +262,38 @@ def test_bench_self_launches_its_ranks():
 def test_bench_two_ranks_self_launched_on_one_gpu():
     """The same command form on the GPU box: `python bench.py --gpus 2` starts two ranks that share the one card (GDB_BENCH_REHEARSE=1:
     gloo, the all-gather staged through host memory - a rehearsal of the product path, never a measurement).  The line must carry
-    what an N > 1 record is graded on: both modes (headline: independent frames, weak scaling), the gathered strips equal to the
-    full render, every rank's kernel time and roofline fraction, and rank 0's CPU baseline."""
+    what an N > 1 record is graded on.  Headline = north_star's partitioning: ONE frame, row strips, one
+    all-gather, strong scaling - with the gathered strips equal to the full render, every rank's prepare / kernel / all-gather time and
+    bus GB/s, the same protocol on c4 (`rows_c4`; c5 is left out of this test for its size), the independent-frames record beside it,
+    and rank 0's CPU baseline."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(GDB_BENCH_REHEARSE="1")
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50", "--rows-extra", "c4"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
     rec = json.loads(lines[0])
-    # headline = every rank its own frame (weak scaling, no data-path collective); the one-frame row split + all-gather rides along
-    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
-    rows = rec["single_frame_rows"]
-    assert rec["gathered_equals_full_render"] is True and rows["gathered_equals_full_render"] is True and rows["scaling"] == "strong"
-    assert rows["allgather_bytes_per_rank"] > 0 and rows["value"] > 0 and rec["config"]["shard"] == "frames"
-    assert sorted(r["rank"] for r in rec["per_rank"]) == [0, 1]
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["shard"] == "rows"
+    assert rec["mode"].startswith("rows:") and rec["gathered_equals_full_render"] is True and "gloo" in rec["collective"]
+    assert rec["allgather_bytes_per_rank"] > 0 and rec["allgather_ms"] > 0 and rec["bus_GBps"] > 0 and rec["prepare_ms"] > 0
+    rr = rec["rows_per_rank"]
+    assert sorted(r["rank"] for r in rr) == [0, 1] and rr[0]["rows"] == [0, 128] and rr[1]["rows"] == [128, 256]
+    assert all(r["kernel_ms"] > 0 and r["prepare_ms"] > 0 and r["allgather_ms"] > 0 and r["gathered_equals_full_render"] is True for r in rr)
     assert all(r["kernel_ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in rec["per_rank"])
-    assert rec["per_rank"][0]["rows"] == [0, 128] and rec["per_rank"][1]["rows"] == [128, 256]   # (the strips of the rows record)
-    # ... and `--shard rows` puts the strong-scaling record on top
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50", "--shard", "rows", "--no-cpu-baseline"],
+    c4 = rec["rows_c4"]
+    assert c4["gathered_equals_full_render"] is True and c4["scaling"] == "strong" and c4["value"] > 0 and c4["kernel"] == "k_render_dense"
+    assert [r["rows"] for r in c4["per_rank"]] == [[0, 200], [200, 400]]
+    fr = rec["independent_frames"]
+    assert fr["scaling"] == "weak" and fr["value"] > 0
+    assert rec["cpu_baseline"]["cores"] == 8 and rec["cpu_baseline"]["value"] > 0
+    # ... and `--shard frames` puts the weak-scaling record on top
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm-ms", "50", "--shard", "frames", "--no-cpu-baseline", "--rows-extra", ""],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     rec2 = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
-    assert rec2["scaling"] == "strong" and rec2["gathered_equals_full_render"] is True and "independent_frames" in rec2
-    assert rec["cpu_baseline"]["cores"] == 8 and rec["cpu_baseline"]["value"] > 0
+    assert rec2["scaling"] == "weak" and rec2["gathered_equals_full_render"] is True and rec2["single_frame_rows"]["scaling"] == "strong"

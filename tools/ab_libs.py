@@ -20,6 +20,13 @@ def child(cases, steps):
             if not hasattr(probe, name):
                 del _lib._SIGNATURES[name]
         _lib.ABI_VERSION = probe.gdb_abi_version()
+        if not hasattr(probe, "gdb_render_info"):   # ABI < 6: the rule the engine then restated in Python (round 4's gdb_fixed_counts_dense)
+            from gdb_nerf_amd import engine as _eng0
+            _eng0.HotPathEngine.render_info = lambda self, *a, **k: {"fused": 1, "schedule": 0, "launches": 1, "kernel": None, "plan_built_by_prepare": int(
+                bool(self.cfg.is_adaptive) or ((self.cfg.max_num_samples > 3 or self.cfg.max_num_samples == 2) and self._frame.V <= 3))}
+        if not hasattr(probe, "gdb_prepare_rows"):  # ABI < 6: no strip-only plan
+            L0 = _lib.load()
+            L0.gdb_prepare_rows = lambda cfg, f, fpn, flags, r0, r1, ws, n, st: L0.gdb_prepare_ex(cfg, f, fpn, flags, ws, n, st)
         if not hasattr(probe, "gdb_prepare_ex"):   # ABI < 5: the engine's prepare call expressed in the older entry points
             L = _lib.load()
             L.gdb_prepare_ex = lambda cfg, f, fpn, flags, ws, n, st: (L.gdb_prepare_fpn(cfg, f, fpn, ws, n, st) if fpn else L.gdb_prepare(cfg, f, ws, n, st))
