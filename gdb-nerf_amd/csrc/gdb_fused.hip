@@ -52,7 +52,11 @@ enum {
     F_W0B = 25,   // weight.0 columns [64,88) on [vox|im]: [out tile][k-step]
     F_W0C = 29,   // weight.0 columns [88,111) on the per-view tail: [out tile][k-step]
     F_FHB = 33,   // biases of feat_head / sigma, on the constant-one slot of the [vox | im] operand
-    N_FRAGS = 34
+    // GDB_PREC_F16 only (round 5): the two one-row layers as MFMAs on the ReLU'd accumulator of the layer before (the f16 kernels are
+    // bound by vector instructions, the matrix pipe idles: a 32-term dot product per lane is 32 of them, the operand conversion 16)
+    F_FCA = 34,   // rows 0..15 fc, rows 16 and 20 agg_w_fc (register 8 of BOTH lane halves), on ReLU(G_v): k-steps 0, 1
+    F_W2R = 36,   // rows 0 and 4 weight.2 (register 0 of both lane halves), on ReLU(weight.0's output): [tile][k-step]
+    N_FRAGS = 40
 };
 // Biases ride inside the MFMAs wherever an operand has a spare K slot: that slot of the B operand is set to 1.0
 // and the matching column of the weight fragment holds the bias (view_fc: tail slot 19; global_fc: slot 24 of the
@@ -211,6 +215,15 @@ void gdb_pack_mfma_section(const float* fp32, float* out) {
         }
     }
     p.table(TD_AGG, PW_AGG_W, 1, lt(GDB_GF));
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int r = l & 31, h = l >> 5;
+            for (int i = 0; i < 8; ++i) {
+                const int col = vrow(s, h, i);
+                p.put(F_FCA + s, l * 8 + i, r < GDB_IM ? fp32[PW_FC_W + r * GDB_GF + col] : ((r == 16 || r == 20) ? fp32[PW_AGG_W + col] : 0.f));
+                for (int t = 0; t < 2; ++t) p.put(F_W2R + 2 * t + s, l * 8 + i, (r == 0 || r == 4) ? fp32[PW_W2_W + 32 * t + col] : 0.f);
+            }
+        }
     out[TS_BAGG] = fp32[PW_AGG_B];
     out[TS_BW2] = fp32[PW_W2_B];
 
@@ -721,34 +734,38 @@ __device__ __forceinline__ void wave_prio(bool last_tile, bool gather) {
 // 0, the 4 direction values; from them the two f16 operand fragments of the per-view tail vector
 // tv[32] = [feat ⊕ rgb 19 | 0 | dir 4 at 24..27 | 0].
 template <bool X> struct Tail { float fv[12]; Frag<X> T0, T1; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 h8_of(unsigned a, unsigned b, unsigned c, unsigned d) { const u32x4 v = {a, b, c, d}; return __builtin_bit_cast(half8, v); }
+// GDB_PREC_F16: the staged halves ARE the operand elements.  u[0..3] = this lane's channel pairs of k-step 0 (accumulator registers
+// 0..7 = channels 8s + 4h + e), u[4], u[5] = channels (16, 17), (18, 19 = 0).  Both lane halves read the SAME rows for the k-step-1
+// operand (channels 16..19, the direction code): half 1's k slots there (k = 20..23, 28..31) meet zero weights in every fragment, so
+// what it carries is irrelevant as long as it is finite - and a copy of half 0's values is exactly as finite as those.  (Until round 5
+// half 1 read zeros under an exec mask: four s_and_saveexec / s_or pairs per call, three calls per view.)
+struct TailP { unsigned u[6]; half8 T0, T1; };
+__device__ __forceinline__ TailP load_tailp(const float* __restrict__ st, int j, int h) {
+    constexpr int RF = row_feat<GDB_PREC_F16>(), RD = row_dir<GDB_PREC_F16>();
+    const unsigned* su = (const unsigned*)st + j;
+    TailP t;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) t.u[2 * s + r] = su[(RF + 4 * s + 2 * h + r) * 32];   // channels 8s + 4h + 2r, + 1
+    t.u[4] = su[(RF + 8) * 32]; t.u[5] = su[(RF + 9) * 32];
+    const unsigned d01 = su[(RD + 0) * 32], d23 = su[(RD + 1) * 32];
+    t.T0 = h8_of(t.u[0], t.u[1], t.u[2], t.u[3]);
+    // tv[19] is padding: the constant one that carries view_fc's bias (half 1's twin slot, k = 23, has zero weights)
+    t.T1 = h8_of(t.u[4], (t.u[5] & 0xFFFFu) | 0x3C000000u, d01, d23);   // dir sits at tv[24..27]
+    return t;
+}
 template <bool X>
 __device__ __forceinline__ Tail<X> load_tail(const float* __restrict__ st, int j, int h) {
     constexpr int RF = row_feat<X ? GDB_PREC_F32X : GDB_PREC_F16>(), RD = row_dir<X ? GDB_PREC_F32X : GDB_PREC_F16>();
     Tail<X> t;
-    if constexpr (!X) {   // GDB_PREC_F16: packed channel pairs - the staged halves ARE the operand elements
-        const unsigned* su = (const unsigned*)st + j;
-        _Float16 hv[12];
+    if constexpr (!X) {   // GDB_PREC_F16: packed channel pairs
+        const TailP p = load_tailp(st, j, h);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {   // channels 8s + 4h + 2r, + 1 = packed row 4s + 2h + r
-                const hpair p = unpack_h2(su[(RF + 4 * s + 2 * h + r) * 32]);
-                hv[4 * s + 2 * r] = p.x; hv[4 * s + 2 * r + 1] = p.y;
-            }
-        {   // channels 16 .. 19 (half 0; 19 is stored as 0) / none (half 1)
-            const hpair p = unpack_h2(h == 0 ? su[(RF + 8) * 32] : 0u), q = unpack_h2(h == 0 ? su[(RF + 9) * 32] : 0u);
-            hv[8] = p.x; hv[9] = p.y; hv[10] = q.x; hv[11] = q.y;
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) t.fv[i] = (float)hv[i];
-        const unsigned d01 = h == 0 ? su[(RD + 0) * 32] : 0u, d23 = h == 0 ? su[(RD + 1) * 32] : 0u;
-        const hpair p01 = unpack_h2(d01), p23 = unpack_h2(d23);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t.T0.hi[i] = hv[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t.T1.hi[i] = hv[8 + i];  // channels 16..18 (half 0) / zeros (half 1: ch >= 20)
-        t.T1.hi[3] = (_Float16)(h == 0 ? 1.f : 0.f);           // tv[19] is padding: constant one that carries view_fc's bias
-        t.T1.hi[4] = p01.x; t.T1.hi[5] = p01.y; t.T1.hi[6] = p23.x; t.T1.hi[7] = p23.y;  // dir sits at tv[24..27], owned by half 0
+        for (int i = 0; i < 6; ++i) { const hpair q = unpack_h2(p.u[i]); t.fv[2 * i] = (float)q.x; t.fv[2 * i + 1] = (float)q.y; }
+        t.T0.hi = p.T0; t.T1.hi = p.T1;
         return t;
     }
 #pragma unroll
@@ -1077,8 +1094,11 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
     float dn, ball, xyz[4][3], ctr[3];
     bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
+    // Lanes WITHOUT a sample in this slot gather too (round 5): their bundle and slot are clamped to a real sample of the window (its
+    // coordinates are as valid as any lane's), so the whole gather is straight-line code - no exec-masked region, no zero-initialised
+    // merge values (20 v_mov per view) - and what they stage is finite.  Their results never reach an output (the composite masks them).
     vox[0] = vox[1] = vox[2] = vox[3] = 0.f;  // voxel feature, channels 4h..4h+3   :322-324
-    if (act && !SKIPPED(skip, 4)) {
+    if ((PREC != GDB_PREC_F32X || act) && !SKIPPED(skip, 4)) {
         float gx = gs_coord(q.u, f.W), gy = gs_coord(q.v, f.H), gz = gs_coord(dn, f.D);
         float xf = floorf(gx), yf = floorf(gy), zf = floorf(gz);
         float wy = gy - yf, wz = gz - zf;
@@ -1126,23 +1146,22 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
     target_dir(ctr, tc + T_O, td);
     for (int v = 0; v < V; ++v) {
         float* st = stage + (size_t)v * stage_v<PREC>();
-        // gather_view defines all 22 outputs; lanes without a sample in this slot stage unspecified values (never zeroed:
-        // their columns of the MLP stay their own and their composite record is written as zeros)
         float4 feat[3];
         float dir[4], rgb[2][3];
-        if (act) {
-            if constexpr (PREC == GDB_PREC_F16) gather_view16(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
-            else gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
-        }
-        else {
-            const float u = __builtin_nondeterministic_value(0.f);
-            feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
+        if constexpr (PREC == GDB_PREC_F16) gather_view16(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        else if constexpr (PREC == GDB_PREC_F32) gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        else {   // split-f16 at three waves per SIMD has no register for the straight-line form (it spills one): lanes without a sample skip
+            if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+            else {
+                const float u = __builtin_nondeterministic_value(0.f);
+                feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dir[e] = u;
+                for (int e = 0; e < 4; ++e) dir[e] = u;
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) rgb[e][c] = u;
+                    for (int c = 0; c < 3; ++c) rgb[e][c] = u;
+            }
         }
         constexpr int RF = row_feat<PREC>(), RD = row_dir<PREC>();
         if constexpr (PREC == GDB_PREC_F16) {  // colours as packed halves: row 2c + h = (sub-ray 2h, 2h + 1) of colour c
@@ -1232,13 +1251,15 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     }
     f32x16 base;
     Frag<X> a_view, a_ga0, a_ga1;
-    f32x16 w_agg;
+    f32x16 w_agg;          // split-f16 path only
+    half8 fca0, fca1;      // GDB_PREC_F16 only: fc (+) agg_w_fc on ReLU(G_v)
     {   LANE_KEYS();  // mean / unbiased variance of g_v over views   nerf.py:73
         a_view = load_fragx<X>(mf, F_VIEW, lane_o);
         const Frag<X> gv0 = load_fragx<X>(mf, F_GVAR, lane_o), gv1 = load_fragx<X>(mf, F_GVAR + 1, lane_o);
         const Frag<X> gm0 = load_fragx<X>(mf, F_GMEAN, lane_o), gm1 = load_fragx<X>(mf, F_GMEAN + 1, lane_o);
         a_ga0 = load_fragx<X>(mf, F_GA, lane_o); a_ga1 = load_fragx<X>(mf, F_GA + 1, lane_o);  // next phase
-        w_agg = load_tab(mf, TD_AGG, h_o);
+        if constexpr (X) w_agg = load_tab(mf, TD_AGG, h_o);
+        else { fca0 = load_frag(mf, F_FCA, lane_o); fca1 = load_frag(mf, F_FCA + 1, lane_o); }
         // sum and sum of squares (var = (sum g^2 - V mean^2) / (V - 1)): two instructions per value and view, Welford's update four.
         // Cancellation: 1e-7 |g|^2 absolute on the variance - below what the operand rounding of these two paths does to it for
         // O(1) features (f16 operands: 5e-4 relative; operand pairs: 2.4e-7 relative); the exact-fp32 core (slot_mlp_core_f32)
@@ -1269,6 +1290,54 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     }
     PHASE_FENCE();
     STAMP(3);
+    Frag<X> H0, lr0, lr1, lr2, lr3;
+    if constexpr (!X) {
+        // ---- GDB_PREC_F16 (round 5): per-view global feature, softmax over views, fc - all sums taken on the matrix pipe -------------
+        // im = fc(sum_v a_v ReLU(G_v)) = b_fc + sum_v a_v (W_fc ReLU(G_v)): fc is linear, so the softmax-weighted sum moves BEHIND it and
+        // runs over 16 values (8 registers) instead of 32; the logit agg_w_fc . ReLU(G_v) is row 16 / 20 of the same product (F_FCA), in
+        // register 8 of both lane halves (no cross-half add).  ReLU(G_v) is rounded to f16 once, as the operand it becomes either way.
+        // g_v = feat + ReLU(view_fc(dir)) is formed on the packed halves (its only use here is as an f16 operand): 18 instructions.
+        LANE_KEYS();
+        lr0 = load_fragx<X>(mf, F_LR0, lane_o); lr1 = load_fragx<X>(mf, F_LR0 + 1, lane_o);  // next phase
+        lr2 = load_fragx<X>(mf, F_LR0 + 2, lane_o); lr3 = load_fragx<X>(mf, F_LR0 + 3, lane_o);
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        const f32x8 b_fc = ldu_pin<f32x8>(mf + TB_FC, (unsigned)h_o * 64u);   // registers 0..7 = rows < 16 of the [h][16] table
+        float ia[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ia[i] = 0.f;
+        float mx = -INFINITY, den = 0.f;
+        const half2v z2 = {0, 0};
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const TailP tp = load_tailp(stage + (size_t)v * STAGE_V, j, h);
+            const f32x16 a = MFMA(a_view.hi, tp.T1, zero16());
+            unsigned gp[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                half2v r = {(_Float16)a[2 * q], (_Float16)a[2 * q + 1]};
+                r = __builtin_elementwise_max(r, z2);
+                gp[q] = __builtin_bit_cast(unsigned, (half2v)(r + __builtin_bit_cast(half2v, tp.u[q])));
+            }
+            f32x16 G = MFMA(a_ga0.hi, h8_of(gp[0], gp[1], gp[2], gp[3]), base);
+            G = MFMA(a_ga1.hi, h8_of(gp[4], gp[5], 0u, 0u), G);
+            const half8 R0 = acc_frag<0, true>(G), R1 = acc_frag<1, true>(G);
+            f32x16 t = MFMA(fca0, R0, zero16());
+            t = MFMA(fca1, R1, t);
+            const float sv = relu1(t[8] + b_agg);  // nerf.py:79
+            const float mn = fmaxf(mx, sv);
+            const float sc_old = __expf(mx - mn), e = __expf(sv - mn);
+            den = den * sc_old + e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ia[i] = fmaf(e, t[i], ia[i] * sc_old);
+            mx = mn;
+        }
+        const float r = frcp(den);
+        half8 hh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hh[i] = (_Float16)fmaf(ia[i], r, b_fc[i]);   // im   nerf.py:82
+        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        H0.hi = __builtin_elementwise_max(hh, z8);
+    } else {
     f32x16 agg, im;
     Frag<X> fc0, fc1;
     {   LANE_KEYS();  // per-view global feature, softmax-weighted sum over views (online)   nerf.py:78-80
@@ -1297,13 +1366,13 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
         for (int i = 0; i < 16; ++i) agg[i] *= r;
     }
     PHASE_FENCE();
-    Frag<X> H0, lr0, lr1, lr2, lr3;
     {   LANE_KEYS();  // im = fc(agg)   nerf.py:82
         lr0 = load_fragx<X>(mf, F_LR0, lane_o); lr1 = load_fragx<X>(mf, F_LR0 + 1, lane_o);  // next phase
         lr2 = load_fragx<X>(mf, F_LR0 + 2, lane_o); lr3 = load_fragx<X>(mf, F_LR0 + 3, lane_o);
         im = mm<X>(fc0, accf<0, false, X>(agg), im);
         im = mm<X>(fc1, accf<1, false, X>(agg), im);
         H0 = accf<0, true, X>(im);
+    }
     }
     PHASE_FENCE();
     STAMP(4);
@@ -1350,12 +1419,17 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     }
     PHASE_FENCE();
     Frag<X> c00, c01, c10, c11;
-    f32x16 w20, w21;
+    f32x16 w20, w21;                  // split-f16 path only
+    half8 w2r0, w2r1, w2r2, w2r3;     // GDB_PREC_F16 only: weight.2 on ReLU(weight.0's output), as MFMA fragments
     {   LANE_KEYS();
         // operands of the per-view blend pass (next phase; loop-invariant there: loaded once per slot, not per view)
         c00 = load_fragx<X>(mf, F_W0C + 0, lane_o); c01 = load_fragx<X>(mf, F_W0C + 1, lane_o);
         c10 = load_fragx<X>(mf, F_W0C + 2, lane_o); c11 = load_fragx<X>(mf, F_W0C + 3, lane_o);
-        w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o);
+        if constexpr (X) { w20 = load_tab(mf, TD_W2, h_o); w21 = load_tab(mf, TD_W2 + 32, h_o); }
+        else {
+            w2r0 = load_frag(mf, F_W2R + 0, lane_o); w2r1 = load_frag(mf, F_W2R + 1, lane_o);
+            w2r2 = load_frag(mf, F_W2R + 2, lane_o); w2r3 = load_frag(mf, F_W2R + 3, lane_o);
+        }
         hs1 = mm<X>(wc0, X00, zero16());
         hs1 = mm<X>(wc1, X01, hs1);
         hs1 = mm<X>(wc2, X10, hs1);
@@ -1365,10 +1439,49 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
     }
     PHASE_FENCE();
     STAMP(5);
-    // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb] (online)   nerf.py:108-110
+    // per-view blend weight, softmax-weighted blend of [rgbs | feat | rgb]   nerf.py:108-110
 #pragma unroll
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-    {
+    if constexpr (!X) {
+        // ---- GDB_PREC_F16 (round 5) ------------------------------------------------------------------------------------------------
+        // The logit weight.2 . ReLU(hv) is an MFMA on the ReLU'd, f16-rounded accumulators (F_W2R: rows 0 and 4, i.e. register 0 of both
+        // lane halves) instead of a 64-term dot product on the vector ALU; and the softmax over views takes two passes - the logits first
+        // (left in the view's direction row, dead once its tail operand is in registers), then exp(logit - max) x the staged values -
+        // where the online form rescaled 16 running sums per view.
+        constexpr int RD = row_dir<GDB_PREC_F16>();
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            float* st = const_cast<float*>(stage) + (size_t)v * STAGE_V;
+            const TailP tp = load_tailp(st, j, h);
+            f32x16 hv0 = MFMA(c00.hi, tp.T0, hs0);
+            hv0 = MFMA(c01.hi, tp.T1, hv0);
+            f32x16 hv1 = MFMA(c10.hi, tp.T0, hs1);
+            hv1 = MFMA(c11.hi, tp.T1, hv1);
+            const half8 R00 = acc_frag<0, true>(hv0), R01 = acc_frag<1, true>(hv0), R10 = acc_frag<0, true>(hv1), R11 = acc_frag<1, true>(hv1);
+            f32x16 u = MFMA(w2r0, R00, zero16());
+            u = MFMA(w2r1, R01, u);
+            u = MFMA(w2r2, R10, u);
+            u = MFMA(w2r3, R11, u);
+            const float uv = relu1(u[0] + b_w2);  // nerf.py:109
+            st[RD * 32 + j] = uv;                 // (both lane halves hold the same value and write the same word)
+            mx = fmaxf(mx, uv);
+        }
+        float den = 0.f;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const float* st = stage + (size_t)v * STAGE_V;
+            const float e = __expf(st[RD * 32 + j] - mx);
+            den += e;
+            float val[16];
+            load_blend16<GDB_PREC_F16>(st, j, h, val);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = fmaf(e, val[i], bacc[i]);  // nerf.py:110
+        }
+        const float r = frcp(den);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] *= r;
+    } else {
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {

@@ -19,7 +19,7 @@ from gdb_nerf_amd import _lib, synthetic
 from gdb_nerf_amd.engine import NERF_KEYS
 
 # enum values of gdb_fused.hip (f16 section, then the low-half section behind the f32 section)
-F_VIEW, F_GVAR, F_GMEAN, F_GA, F_FC, F_LR0, F_FH, F_W0A, F_W0B, F_W0C, F_FHB, N_FRAGS = 0, 1, 3, 5, 7, 9, 13, 17, 25, 29, 33, 34
+F_VIEW, F_GVAR, F_GMEAN, F_GA, F_FC, F_LR0, F_FH, F_W0A, F_W0B, F_W0C, F_FHB, F_FCA, F_W2R, N_FRAGS = 0, 1, 3, 5, 7, 9, 13, 17, 25, 29, 33, 34, 36, 40
 TB_FC = N_FRAGS * 256
 TD_AGG, TD_W2 = TB_FC + 32, TB_FC + 64
 TS_BAGG, TS_BW2 = TD_W2 + 64, TD_W2 + 65
@@ -81,8 +81,11 @@ def relu(x):
     return np.maximum(x, np.float32(0))
 
 
-def emulate(secs, vox, x_in, on):
-    """slot_mlp_core<X = on> for n samples: x_in (V, n, 35) per-view vectors, vox (n, 8) -> sigma pre-activation, feat (n, 39)."""
+def emulate(secs, vox, x_in, on, mfma_sums=False):
+    """slot_mlp_core<X = on> for n samples: x_in (V, n, 35) per-view vectors, vox (n, 8) -> sigma pre-activation, feat (n, 39).
+    mfma_sums: the GDB_PREC_F16 form of round 5 - the two one-row layers (agg_w_fc, weight.2) and fc run as MFMAs on the ReLU'd
+    accumulator of the layer before (fragments F_FCA, F_W2R: the logit comes out in register 8 / 0 of BOTH lane halves, i.e. rows
+    16 and 20 / 0 and 4), the softmax-weighted sum over views moves behind fc, g_v is formed on packed halves."""
     hi = secs[0]
     V, n, _ = x_in.shape
     z = np.zeros((32, n), np.float32)
@@ -107,16 +110,27 @@ def emulate(secs, vox, x_in, on):
     G = []
     for v in range(V):
         t = base
+        # (mfma_sums: g_v = staged halves + f16(ReLU(view_fc)), summed in f16)
+        gv = f16(f16(tv[v]) * (np.arange(32) < 19)[:, None] + f16(relu(mm(secs, F_VIEW, b_step(tv[v], 1), z, on)))) if mfma_sums else g[v]
         for s in range(2):
-            t = mm(secs, F_GA + s, b_step(g[v], s), t, on)
+            t = mm(secs, F_GA + s, b_step(gv, s), t, on)
         G.append(relu(t))
     G = np.stack(G)
-    sc = relu(np.einsum("vrn,r->vn", G, w_agg) + b_agg)
-    e = np.exp(sc - sc.max(axis=0)); a_w = (e / e.sum(axis=0)).astype(np.float32)
-    agg = np.einsum("vrn,vn->rn", G, a_w).astype(np.float32)
-    im = np.broadcast_to(table(hi, TB_FC)[:, None], (32, n)).astype(np.float32)
-    for s in range(2):
-        im = mm(secs, F_FC + s, b_step(agg, s), im, on)
+    if mfma_sums:
+        assert not on
+        T = np.stack([mm(secs, F_FCA + 1, b_step(G[v], 1), mm(secs, F_FCA, b_step(G[v], 0), z, on), on) for v in range(V)])
+        assert np.array_equal(T[:, 16], T[:, 20]) and not T[:, 17:20].any() and not T[:, 21:].any()   # the logit, in both lane halves
+        sc = relu(T[:, 16] + b_agg)
+        e = np.exp(sc - sc.max(axis=0)); a_w = (e / e.sum(axis=0)).astype(np.float32)
+        im = (table(hi, TB_FC)[:, None] + np.einsum("vrn,vn->rn", T, a_w)).astype(np.float32)
+        im[16:] = 0
+    else:
+        sc = relu(np.einsum("vrn,r->vn", G, w_agg) + b_agg)
+        e = np.exp(sc - sc.max(axis=0)); a_w = (e / e.sum(axis=0)).astype(np.float32)
+        agg = np.einsum("vrn,vn->rn", G, a_w).astype(np.float32)
+        im = np.broadcast_to(table(hi, TB_FC)[:, None], (32, n)).astype(np.float32)
+        for s in range(2):
+            im = mm(secs, F_FC + s, b_step(agg, s), im, on)
     H0 = b_step(relu(im), 0)
     H1 = np.zeros((16, n), np.float32)
     for h in range(2):
@@ -138,9 +152,15 @@ def emulate(secs, vox, x_in, on):
     w2 = [table(hi, TD_W2 + 32 * t) for t in range(2)]
     up = np.zeros((V, n), np.float32)
     for v in range(V):
+        u = z
         for t in range(2):
             hv = mm(secs, F_W0C + 2 * t + 1, b_step(tv[v], 1), mm(secs, F_W0C + 2 * t, b_step(tv[v], 0), hs[t], on), on)
             up[v] += np.einsum("rn,r->n", relu(hv), w2[t])
+            for s in range(2):
+                u = mm(secs, F_W2R + 2 * t + s, b_step(relu(hv), s), u, on)
+        if mfma_sums:
+            assert np.array_equal(u[0], u[4]) and not u[1:4].any() and not u[5:].any()   # the logit, in both lane halves
+            up[v] = u[0]
     up = relu(up + hi[TS_BW2])
     e = np.exp(up - up.max(axis=0)); bw = (e / e.sum(axis=0)).astype(np.float32)
     blended = np.einsum("vnc,vn->nc", x_in[:, :, :31], bw)
@@ -178,12 +198,13 @@ def test_f16_sections_reproduce_the_mlp(V, viewdir):
     vox = rng.standard_normal((ns, 8)).astype(np.float32)
     osig, ofeat = oracle.nerf_mlp(w, vox, x_in, viewdir_agg=viewdir)
     err = {}
-    for on in (False, True):
-        sig, feat = emulate((hi, lo), vox, x_in, on)
+    for on in (False, True, "mfma_sums"):
+        sig, feat = emulate((hi, lo), vox, x_in, on is True, mfma_sums=on == "mfma_sums")
         err[on] = (np.abs(feat - ofeat).max() / max(1.0, np.abs(ofeat).max()),
                    np.abs(oracle._softplus(sig[:, None])[:, 0] - osig).max() / max(1.0, np.abs(osig).max()))
-    print(f"V={V} viewdir={viewdir}: f16 operands {err[False]}, split-f16 pairs {err[True]}")
+    print(f"V={V} viewdir={viewdir}: f16 operands {err[False]}, with the MFMA sums of round 5 {err['mfma_sums']}, split-f16 pairs {err[True]}")
     assert max(err[False]) <= 1e-3          # f16 operands: the layout is right, the precision is f16's
+    assert max(err["mfma_sums"]) <= 1e-3    # ... and so is the form GDB_PREC_F16 runs since round 5
     assert max(err[True]) <= 1e-6           # hi + lo pairs: fp32-grade, the bound the f32-MFMA section meets
 
 
