@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
         t1.p00 = b0; t1.p10 = b1; t1.p01 = b2; t1.p11 = b3; t1.edge = b4; t1.w00 = b5; t1.w10 = b6; t1.w01 = b7; t1.w11 = b8;
     }
     const unsigned o0 = 2u * (l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3))), hw0 = __umul24(f.W >> l0, f.H >> l0);
-    const bool two = frac > 0.f && do_tex;
+    const unsigned o1 = 2u * (l1 == 0 ? 0u : (l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3))), hw1 = __umul24(f.W >> l1, f.H >> l1);
     RgbTaps rt[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
@@ -1066,16 +1066,17 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
         rt[e] = rgb_taps16(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
     }
     // ---- issue: level 0 and both sub-rays' colours in flight together (6 + 4 loads) ---------------------------------------------
+    // (Measured, round 5 - profiles/r05/ab_f16_both_levels_in_flight.txt: level 1 fetched unconditionally - its products are exact zeros
+    // when frac = 0 - and issued beside level 0, one exposed round trip per view instead of two, is SLOWER: c2 39.9 -> 41.2 us, c5 680 ->
+    // 720.  The texture addresser is 67 % busy at c5; twelve more loads in flight per wave cost more than the second round trip.)
+    const bool two = frac > 0.f && do_tex;
     TapData16s d0, d1;
     RgbData16 rd[2];
     if (do_tex) taps_load16s(pyr, t0, o0, hw0, h, d0);
     if (do_rgb) { rgb_load16(img, rt[0], rd[0]); rgb_load16(img, rt[1], rd[1]); }
     if (do_tex) taps_acc16s<true>(t0, d0, h, feat);
     else feat[0] = feat[1] = feat[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (two) {
-        const unsigned o1 = 2u * (l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3)), hw1 = __umul24(f.W >> l1, f.H >> l1);
-        taps_load16s(pyr, t1, o1, hw1, h, d1);
-    }
+    if (two) taps_load16s(pyr, t1, o1, hw1, h, d1);
     if (do_rgb) { rgb_combine16(rt[0], rd[0], rgb[0]); rgb_combine16(rt[1], rd[1], rgb[1]); }
     else { for (int e = 0; e < 2; ++e) for (int c = 0; c < 3; ++c) rgb[e][c] = 0.f; }
     if (two) taps_acc16s<false>(t1, d1, h, feat);
@@ -1459,7 +1460,7 @@ __device__ __forceinline__ void slot_mlp_core(const DevFrame& f, const float* __
             f32x16 hv1 = MFMA(c10.hi, tp.T0, hs1);
             hv1 = MFMA(c11.hi, tp.T1, hv1);
             const half8 R00 = acc_frag<0, true>(hv0), R01 = acc_frag<1, true>(hv0), R10 = acc_frag<0, true>(hv1), R11 = acc_frag<1, true>(hv1);
-            f32x16 u = MFMA(w2r0, R00, zero16());
+            f32x16 u = MFMA(w2r0, R00, zero16());   // (one chain of four: a second accumulator is 16 registers at this kernel's register peak - it spilled)
             u = MFMA(w2r1, R01, u);
             u = MFMA(w2r2, R10, u);
             u = MFMA(w2r3, R11, u);
@@ -2944,21 +2945,29 @@ static int render_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr,
             if (rc) return rc;
         }
         a.alias = 0;
-        // the 3-waves-per-SIMD build (168 registers) wherever LDS admits more than the 8 waves per CU of the 2-wave build
+        // the 3-waves-per-SIMD build (168 registers) wherever LDS admits more than the 8 waves per CU of the 2-wave build.
+        // GDB_PREC_F16 (round 5): its list kernels need 142 registers whatever they are allowed (so there is no 2-wave build of them), and
+        // fit into the 128 of FOUR waves per SIMD without a spill: that build wherever LDS admits all 16 waves per CU (V <= 4; c2 f16 42.2 ->
+        // 39.8 us, c3 71.3 -> 67.0, c4 81.9 -> 78.2.  At V = 5 LDS admits 14, and the 4-wave build with 14 is SLOWER than the 3-wave one with
+        // 12: c5 forced onto this schedule 744 -> 777 us, profiles/r05/ab_f16_four_waves.txt).
+        const size_t by_lds = waves_by_lds(solo_lds + pad) > 2 * waves_by_lds(2 * (solo_lds + pad)) ? waves_by_lds(solo_lds + pad) : 2 * waves_by_lds(2 * (solo_lds + pad));
         bool three = false;
-        if constexpr (PREC != GDB_PREC_F32) three = waves_by_lds(solo_lds + pad) > 8 || 2 * waves_by_lds(2 * (solo_lds + pad)) > 8;
+        if constexpr (PREC == GDB_PREC_F32X) three = by_lds > 8;
+        const bool four = PREC == GDB_PREC_F16 && by_lds >= 16;
         const size_t lds = (solo_lds + pad + 15) / 16 * 16;
         if (run == GDB_SCHED_FLAT) {
             const int max_tiles = (int)(((long long)fr->H * fr->W * S + 31) / 32 + 1);
-            if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_flat<PREC, 3>(a, lds, max_tiles, st); }
-            if (!three) e = launch_flat<PREC, 2>(a, lds, max_tiles, st);
+            if constexpr (PREC == GDB_PREC_F16) e = launch_flat<PREC, 3>(a, lds, max_tiles, st);   // (the flat body spills 7 registers at four waves per SIMD)
+            else if constexpr (PREC == GDB_PREC_F32X) e = three ? launch_flat<PREC, 3>(a, lds, max_tiles, st) : launch_flat<PREC, 2>(a, lds, max_tiles, st);
+            else e = launch_flat<PREC, 2>(a, lds, max_tiles, st);
             if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_flat: %s", hipGetErrorString(e));
             return GDB_OK;
         }
         a.ntiles = a.nrows * a.f.planMW;  // per batch item, worst case (every bundle at S_max)
         grid = (unsigned)((a.ntiles + 7) / 8 * 8);
-        if constexpr (PREC != GDB_PREC_F32) { if (three) e = launch_dense<PREC, 3>(a, lds, st); }
-        if (!three) e = launch_dense<PREC, 2>(a, lds, st);
+        if constexpr (PREC == GDB_PREC_F16) e = four ? launch_dense<PREC, 4>(a, lds, st) : launch_dense<PREC, 3>(a, lds, st);
+        else if constexpr (PREC == GDB_PREC_F32X) e = three ? launch_dense<PREC, 3>(a, lds, st) : launch_dense<PREC, 2>(a, lds, st);
+        else e = launch_dense<PREC, 2>(a, lds, st);
     } else if (run == GDB_SCHED_SEGMENT_WAVE) {  // one wave per segment, all slots in turn
         a.alias = 0;
         // three waves per SIMD only where LDS admits them (12 one-wave workgroups per CU) and the precision's register budget does
