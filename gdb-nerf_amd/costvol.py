@@ -15,9 +15,6 @@ def _c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-_PAIR_WS = {}
-
-
 def build_feature_volume(src_feat, src_exts, src_ints, tar_exts, tar_ints, depth_values, inv_depth: bool, pair_layout: bool = True) -> torch.Tensor:
     """pair_layout: let the library re-lay the source maps channel-pair-interleaved first (even C, V <= 4): bit-identical, faster."""
     lib = _lib.load()
@@ -30,15 +27,11 @@ def build_feature_volume(src_feat, src_exts, src_ints, tar_exts, tar_ints, depth
                                   (tar_ints, "tar_ints"), (depth_values, "depth_values"))]
     out = torch.empty((B, Cc, D, Ht, Wt), device=src_feat.device)
     ws = torch.empty((B * V * 12,), device=src_feat.device)
-    # scratch for the channel-pair copy of the source maps (the sweep then loads 16 bytes per channel pair): cached per size
+    # scratch for the channel-pair copy of the source maps (the sweep then loads 16 bytes per channel pair).  Allocated per call:
+    # torch's caching allocator hands the block back without a device allocation and keeps it stream-safe (a module-level cache keyed
+    # by size was shared by every caller on every stream, and the cascade's two stage sizes evicted each other: ADVICE r04)
     n_pair = B * V * Cc * Hs * Ws if (pair_layout and Cc % 2 == 0 and V <= 4) else 0
-    pw = None
-    if n_pair:
-        key = (src_feat.device, n_pair)
-        pw = _PAIR_WS.get(key)
-        if pw is None:
-            _PAIR_WS.clear()
-            pw = _PAIR_WS[key] = torch.empty((n_pair,), device=src_feat.device)
+    pw = torch.empty((n_pair,), device=src_feat.device) if n_pair else None
     _lib.check(lib.gdb_build_feature_volume_ws(*(t.data_ptr() for t in args), B, V, Cc, Hs, Ws, D, Ht, Wt, int(bool(inv_depth)),
                                                ws.data_ptr(), None if pw is None else pw.data_ptr(), out.data_ptr(),
                                                torch.cuda.current_stream(src_feat.device).cuda_stream))

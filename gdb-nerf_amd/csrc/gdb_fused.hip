@@ -1676,7 +1676,8 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         // channels (20..22) do not exist: the mean chain then needs 8 steps instead of 12
         swap32_3(m2[8], mean[8], m2[9], mean[9], m2[10], mean[10]);
         // global_fc: bias + W[:,19:38] var + W[:,38:57] mean, shared by all views   nerf.py:77-78
-        base = chain32w<12>(wv, m2, base);
+        // (11 steps, not 12: register 11 carries channels 19 / 23, which do not exist - its weight step is all zeros, as is Q_GA's)
+        base = chain32w<11>(wv, m2, base);
         base = chain32w<8>(wm, mean, base);
     }
     PHASE_FENCE();
@@ -1695,7 +1696,7 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         for (int v = 0; v < V; ++v) {
             float g[12];
             view_g32(load_tail32<true>(stage + (size_t)v * STAGE_V, j, h), q_view, b_view, g);
-            const f32x16 G = chain32w<12>(wg, g, base);
+            const f32x16 G = chain32w<11>(wg, g, base);
             float sp = dot16_relu(G, w_agg);
             float sv = relu1(sp + __shfl_xor(sp, 32) + b_agg);  // nerf.py:79
             float mn = fmaxf(mx, sv);
@@ -1777,22 +1778,30 @@ __device__ __forceinline__ void slot_mlp_core_f32(const DevFrame& f, const float
         f32x4 wc1[3];
         load_quads<12>(m32, Q_W0C + 3, lane_o, wc1);
         const f32x16 w21 = load_tab(m32, T32_W2 + 32, h_o);
+        // Two passes over the views (round 5): the logits first - each left in the first direction row of its view, dead once the tail
+        // operand is in registers - then exp(logit - max) x the staged values; the online form rescaled 16 running sums per view, and a
+        // vector instruction is matrix time on the fp32 datapath.
+        constexpr int RD = row_dir<GDB_PREC_F32>();
         float mx = -INFINITY, den = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            const float* st = stage + (size_t)v * STAGE_V;
+            float* st = const_cast<float*>(stage) + (size_t)v * STAGE_V;
             const Tail32 t = load_tail32<false>(st, j, h);
             float up = dot16_relu(chain32w<12>(wc0, t.fv, hs0), w20);
             up += dot16_relu(chain32w<12>(wc1, t.fv, hs1), w21);
-            float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
-            float mn = fmaxf(mx, uv);
-            float sc_old = __expf(mx - mn), e = __expf(uv - mn);
-            den = den * sc_old + e;
+            const float uv = relu1(up + __shfl_xor(up, 32) + b_w2);  // nerf.py:109
+            st[RD * 32 + j] = uv;   // (both lane halves hold the same value and write the same word)
+            mx = fmaxf(mx, uv);
+        }
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            const float* st = stage + (size_t)v * STAGE_V;
+            const float e = __expf(st[RD * 32 + j] - mx);
+            den += e;
             float val[16];
             load_blend16<GDB_PREC_F32>(st, j, h, val);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bacc[i] = bacc[i] * sc_old + e * val[i];  // nerf.py:110
-            mx = mn;
+            for (int i = 0; i < 16; ++i) bacc[i] = fmaf(e, val[i], bacc[i]);  // nerf.py:110
         }
         float r = frcp(den);
 #pragma unroll
