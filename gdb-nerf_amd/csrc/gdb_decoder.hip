@@ -52,9 +52,10 @@ typedef unsigned U2 __attribute__((ext_vector_type(2)));
 // ---- packed weights -------------------------------------------------------------------------------------------------
 // conv_floats(cin, nt): floats of a packed layer of 32 nt output channels (fp32 form pack_conv16 and split-f16 form pack_conv_x alike).
 static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 9 * 8 * 64 * 2 * nt; }
+#define DEC_MAX_LAYERS 16   // dense blocks (decoder_rdn.py:57 takes any count; every config of the reference has 3)
 struct DecLayout {
-    size_t in_w, in_b, blk[3][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
-    size_t in_wx, blkx[3][3], up_wx;  // the same convolutions as split-f16 fragments (pack_conv_x), behind the fp32 ones
+    size_t in_w, in_b, blk[DEC_MAX_LAYERS][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
+    size_t in_wx, blkx[DEC_MAX_LAYERS][3], up_wx;  // the same convolutions as split-f16 fragments (pack_conv_x), behind the fp32 ones
     size_t total;
 };
 static DecLayout dec_layout(int nlayers) {
@@ -124,7 +125,7 @@ static void pack_conv_x(const float* w, int cout, int cin, int nt, float* out) {
 static int dec_check(const GdbConfig* cfg, int nlayers) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "the HIP decoder is built for bundle_size 2 (one up stage); got %d", cfg->bundle_size);
-    if (nlayers < 1 || nlayers > 3) return gdb_fail(GDB_E_BADARG, "decoder layers %d outside 1..3", nlayers);
+    if (nlayers < 1 || nlayers > DEC_MAX_LAYERS) return gdb_fail(GDB_E_BADARG, "decoder layers %d outside 1..%d", nlayers, DEC_MAX_LAYERS);
     return GDB_OK;
 }
 
@@ -183,8 +184,9 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
 }
 
 // ---- workspace -------------------------------------------------------------------------------------------------------
-// Activations are (pixels, 64) buffers: P[b] = the input x of dense block b (P[0] = in_conv's output, kept to the end as the decoder's
-// global residual), Y = [x1 | x2] of the block in flight, T = conv3's output; the dense block's torch.cat([x, x1, x2]) is "chunks 0-1
+// Activations are (pixels, 64) buffers: the input x of dense block b (block 0's = in_conv's output, kept to the end as the decoder's
+// global residual, in P[0]; block b >= 1's in P[1 + (b - 1) % 2]: a block reads its predecessor's x and writes its own, so two buffers
+// alternate whatever the number of blocks), Y = [x1 | x2] of the block in flight, T = conv3's output; the dense block's torch.cat([x, x1, x2]) is "chunks 0-1
 // from P[b], chunks 2-3 from Y".  part = per-(row, 32-pixel segment) channel sums of T (written by conv3's epilogue), part2 = their
 // sums per group of DEC_SEG segments, gate = the block's 64 gates per batch item, count = one arrival counter per batch item.
 #ifndef DEC_SEG
@@ -720,7 +722,8 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
         return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging byte offsets");
     const DecLayout L = dec_layout(num_layers);
     hipStream_t st = (hipStream_t)stream_;
-    float* P[3] = {(float*)((char*)d_ws + ws.P[0]), (float*)((char*)d_ws + ws.P[1]), (float*)((char*)d_ws + ws.P[2])};
+    float* Pbuf[3] = {(float*)((char*)d_ws + ws.P[0]), (float*)((char*)d_ws + ws.P[1]), (float*)((char*)d_ws + ws.P[2])};
+    auto Px = [&](int b) -> float* { return b == 0 ? Pbuf[0] : Pbuf[1 + ((b - 1) & 1)]; };   // the input x of dense block b
     float* Y = (float*)((char*)d_ws + ws.Y); float* T = (float*)((char*)d_ws + ws.T);
     float* part = (float*)((char*)d_ws + ws.part); float* part2 = (float*)((char*)d_ws + ws.part2);
     float* gate = (float*)((char*)d_ws + ws.gate); unsigned* count = (unsigned*)((char*)d_ws + ws.count);
@@ -759,19 +762,19 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
         ConvArgs a{};
         a.in = d_bundle_feat; a.in_stride = ld_bundle_feat; a.in_off = n_rgb; a.cin = Q - n_rgb;
         a.w = d_packed + (split ? L.in_wx : L.in_w); a.bias = d_packed + L.in_b;
-        a.out = P[0]; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.zero = count;
+        a.out = Px(0); a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0; a.zero = count;
         CK(conv(a, 2));
     }
     for (int b = 0; b < num_layers; ++b) {   // ResidualDenseBlock.forward   decoder_rdn.py:35-41
         ConvArgs a{};
         a.in_stride = DEC_NF; a.in_off = 0; a.out = Y; a.out_stride = DEC_NF; a.relu = 1;
         // conv1; from the second block on it first forms its own input x_b = x_{b-1} + x3_{b-1} * gate_{b-1} (:40) and leaves it in P[b]
-        a.in = b ? P[b - 1] : P[0];
-        if (b) { a.fT = T; a.fgate = gate; a.fX = P[b]; }
+        a.in = b ? Px(b - 1) : Px(0);
+        if (b) { a.fT = T; a.fgate = gate; a.fX = Px(b); }
         a.cin = DEC_NF; a.w = d_packed + (split ? L.blkx[b][0] : L.blk[b][0]); a.out_off = 0; a.cout = DEC_G;
         CK(conv(a, 1));
         a.fT = nullptr; a.fgate = nullptr; a.fX = nullptr;
-        a.in = P[b]; a.in2 = Y; a.split = 2;
+        a.in = Px(b); a.in2 = Y; a.split = 2;
         a.cin = DEC_NF + DEC_G; a.w = d_packed + (split ? L.blkx[b][1] : L.blk[b][1]); a.out_off = DEC_G;
         CK(conv(a, 1));
         a.cin = DEC_NF + 2 * DEC_G; a.w = d_packed + (split ? L.blkx[b][2] : L.blk[b][2]); a.out = T; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
@@ -783,8 +786,8 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     }
     {   // out_conv(PixelShuffle(up(x + shallow))) as one folded 64 -> 12 convolution on x = x_{L-1} + x3 * gate + shallow   :40,78-80
         ConvArgs a{};
-        a.in = P[num_layers - 1]; a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
-        a.fT = T; a.fgate = gate; a.fS = P[0];
+        a.in = Px(num_layers - 1); a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
+        a.fT = T; a.fgate = gate; a.fS = Px(0);
         a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
         a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
         CK(conv(a, 1));

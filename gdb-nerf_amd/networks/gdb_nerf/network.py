@@ -54,9 +54,10 @@ class Network(nn.Module):
         # "f32x" (split-f16 operand pairs: fp32-grade at close to the f16 rate)
         self.precision = {"f32": 1, "f16": 0, "f32x": 2}[str(getattr(nrf, "precision", "f32"))]
         # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
-        # False keeps the PyTorch-ROCm module.  The HIP decoder is built for bundle_size 2 (one up stage) and 1..3 dense blocks:
-        # any other shape keeps the PyTorch module, as before.
-        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2 and 1 <= int(self.dec_layers) <= 3
+        # False keeps the PyTorch-ROCm module.  The HIP decoder takes any number of dense blocks up to 16 (every reference config has 3) and
+        # is built for bundle_size 2 (one up stage, folded with out_conv): b = 4 - which the fused hot path does not take either - keeps
+        # the PyTorch module.
+        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2 and 1 <= int(self.dec_layers) <= 16
         # Multi-GPU: "rows" = when torch.distributed is initialised, every rank renders one contiguous strip of
         # bundle-map rows of the frame and ONE all-gather of the packed rows (RCCL over xGMI) leaves the whole bundle map on every
         # rank; decoder and merge then run replicated (the decoder's squeeze-excitation takes a global mean over the image,

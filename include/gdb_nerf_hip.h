@@ -344,7 +344,7 @@ int gdb_merge_packed(const GdbConfig* cfg, const GdbFrame* shape, const float* d
 /* Decoder.forward, networks/gdb_nerf/decoder_rdn.py:44-81 (instantiated at network.py:51 as Decoder(C_f+3+C_v, 3, num_feats=64,
  * num_layers=nerf.dec_layers, upscale_factor=b); called at network.py:170-175): in_conv, num_layers ResidualDenseBlocks with
  * squeeze-excitation, up-conv + PixelShuffle, 1x1 out_conv — 3x3 convolutions as implicit GEMMs on fp32 MFMA, channel-last.
- * bundle_size 2 only (one up stage).
+ * bundle_size 2 only (one up stage); num_layers 1 .. 16 (two activation buffers alternate between the blocks).
  *
  * gdb_pack_decoder_weights: h_tensors in state-dict order — in_conv.weight (64,C_in,3,3), in_conv.bias, then per block
  * conv1.weight (32,64,3,3), conv2.weight (32,96,3,3), conv3.weight (64,128,3,3), se.fc.0.weight (4,64), se.fc.2.weight (64,4),

@@ -143,7 +143,7 @@ def test_hip_decoder_matches_the_reference_fixture(prec):
 
 @pytest.mark.gpu
 @PRECS
-@pytest.mark.parametrize("B,H,W,layers", [(1, 32, 48, 3), (2, 19, 45, 3), (1, 7, 33, 2), (1, 256, 320, 3), (1, 130, 70, 1)])
+@pytest.mark.parametrize("B,H,W,layers", [(1, 32, 48, 3), (2, 19, 45, 3), (1, 7, 33, 2), (1, 256, 320, 3), (1, 130, 70, 1), (1, 40, 72, 5), (2, 24, 40, 4)])
 def test_hip_decoder_matches_torch_module(B, H, W, layers, prec):
     """Ragged bundle maps (edges inside a 32-pixel tile and inside a row group), batch 2, 1..3 blocks, and the DTU-eval size
     (two rows per wave), against the PyTorch module on the same GPU."""

@@ -55,12 +55,14 @@ def test_network_has_reference_checkpoint_layout(f7):
 
 
 def test_decoder_gating_and_packed_weight_invalidation(monkeypatch):
-    """The HIP decoder is built for bundle_size 2 and 1..3 dense blocks: any other decoder keeps the PyTorch module (as before it
-    existed).  Its packed weights are re-packed whenever a parameter's storage or version changes - `p.data = ...`,
+    """The HIP decoder is built for bundle_size 2 and 1..16 dense blocks (any count the reference's Decoder takes, capped): any other
+    decoder keeps the PyTorch module (as before it existed).  Its packed weights are re-packed whenever a parameter's storage or version changes - `p.data = ...`,
     load_state_dict(assign=True) and load_state_dict itself included; an in-place write through `.data` (which PyTorch does not
     version) needs invalidate_packed_weights()."""
     from gdb_nerf_amd.networks.gdb_nerf import network as netmod
-    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "4"])).hip_decoder is False
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "17"])).hip_decoder is False
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "4"])).hip_decoder is True
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "4"])).hip_decoder is False
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "3"])).hip_decoder is True
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.hip_decoder", "False"])).hip_decoder is False
 

@@ -206,7 +206,7 @@ def test_f32_mfma_section_reproduces_the_mlp(V, viewdir):
     arrs = [np.ascontiguousarray(w[k + s]) for k in NERF_KEYS for s in (".weight", ".bias")]
     ptrs = (C.c_void_p * 18)(*[a.ctypes.data for a in arrs])
     assert lib.gdb_pack_weights(C.byref(cfg), ptrs, host.ctypes.data) == 0
-    XLO_FLOATS = 34 * 256  # the low-half fragments of GDB_PREC_F32X follow the f32 section (tests/test_pack_f16_sections.py)
+    XLO_FLOATS = 40 * 256  # (N_FRAGS x 256) the low-half fragments of GDB_PREC_F32X follow the f32 section (tests/test_pack_f16_sections.py)
     sec = host[n.value - XLO_FLOATS - F32SEC_FLOATS:n.value - XLO_FLOATS]
     rng = np.random.default_rng(11)
     ns = 64
