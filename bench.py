@@ -520,7 +520,7 @@ def main():
         return ms
 
     # ---- N > 1, rows mode: one frame, row strips, packed output, one all-gather --------------------------------------
-    def rows_record(wl_name, wl_, frame_np_, steps, warmup, eng_=None):
+    def rows_record(wl_name, wl_, frame_np_, steps, warmup, eng_=None, pname_=None):
         """north_star's partitioning of ONE frame of workload `wl_name` over the ranks: contiguous bundle-map row strips; every rank
         prepares (whole pyramid, strip-only plan), renders its strip straight into the packed buffer and ONE all-gather leaves all rows
         on every rank.  Returns the record (rank-0 view + every rank's prepare / kernel / all-gather times)."""
@@ -531,9 +531,10 @@ def main():
         nr = args.frame_ring if args.frame_ring > 0 else max(1, min(8, -(-(320 << 20) // nbytes)))
         rg = [fr] + [{k: v.clone() for k, v in fr.items()} for _ in range(nr - 1)]
         e = eng_
+        pname_ = pname_ or args.precision   # (c5 rides along at f16: BASELINE.json configs[4] names the fp16 MFMA path)
         if e is None:
             e = HotPathEngine(max_num_samples=wl_["S"], is_adaptive=wl_["adaptive"], device=dev)
-            e.set_schedule(args.schedule); e.precision = prec; e.load_weights(weights_np)
+            e.set_schedule(args.schedule); e.precision = PREC[pname_]; e.load_weights(weights_np)
         g = StripGather(H_, W_, e.Q + 2, world, rank, dev, dist, stage_cpu=rehearse)
         r0_, r1_ = g.strip
         ri = [0]
@@ -573,7 +574,8 @@ def main():
                "allgather_bytes_per_rank": g.nbytes, "bus_GBps": mine["bus_GBps"],
                "collective": "gloo (rehearsal, staged through host memory)" if rehearse else "RCCL all_gather_into_tensor, in place" if g.even else "RCCL all_gather_into_tensor, padded",
                "world_size": world, "gathered_equals_full_render": all(p["gathered_equals_full_render"] for p in per),
-               "kernel": e.render_info(None, r0_, r1_)["kernel"], "strip_mfma_frac": (af_ / (mine["kernel_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.precision]) if mine["kernel_ms"] else None,
+               "kernel": e.render_info(None, r0_, r1_)["kernel"], "strip_mfma_frac": (af_ / (mine["kernel_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[pname_]) if mine["kernel_ms"] else None,
+               "precision": pname_, "dtype": DTYPE[pname_],
                "n_samples": n_s, "frame_ring": nr, "per_rank": per}
         del g, rg, fr
         return rec, e, (r0_, r1_)
@@ -612,7 +614,8 @@ def main():
             try:
                 w2 = dict(WORKLOADS[name])
                 k2 = max(20, min(args.steps, 200 if name != "c5" else 60))
-                extra["rows_" + name] = rows_record(name, w2, synthetic.make_frame(w2["Ho"], w2["Wo"], V=w2["V"], scene=w2["scene"], seed=0), k2, min(args.warmup, 20))[0]
+                extra["rows_" + name] = rows_record(name, w2, synthetic.make_frame(w2["Ho"], w2["Wo"], V=w2["V"], scene=w2["scene"], seed=0), k2, min(args.warmup, 20),
+                                                    pname_="f16" if name == "c5" else None)[0]
             except Exception as ex:  # extras never take the headline down
                 extra["rows_" + name] = {"error": repr(ex)}
         if rows_mode:
