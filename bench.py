@@ -624,10 +624,13 @@ def main():
                                                    "gathered_equals_full_render", "mode")})
             extra["rows_per_rank"] = rec_rows["per_rank"]
             extra["independent_frames"] = rec_frames
+            # both figures under names that do not depend on which mode is the headline (a stable key across rounds)
+            extra["value_strong_rows"] = rec_rows["value"]; extra["value_weak_frames"] = rec_frames["value"]
             kern_ms_override = rec_rows["kernel_ms"]
         else:
             dt, rays_per_step, share = dt_frames, world * Ho * Wo, 1.0
             extra["single_frame_rows"] = rec_rows
+            extra["value_strong_rows"] = rec_rows["value"]; extra["value_weak_frames"] = rec_frames["value"]
             extra.update({"world_size": world, "gathered_equals_full_render": rec_rows["gathered_equals_full_render"]})
             kern_ms_override = kern_frames
         eng.prepare(frame)
