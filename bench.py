@@ -212,6 +212,33 @@ def cpu_baseline(wl, frame, weights, quick=False):
                       f"the os.cpu_count() = {ncpu} row on c1 only (c1_rows); numpy oracle: 2 frames, first dropped"}
 
 
+def b4_record(dev, weights_np, fused_ns_per_ray, steps=100):
+    """What `nerf.bundle_size: 4` costs (configs/dtu_pretrain.yaml:33 "4 for 4*4", networks/gdb_nerf/network.py:31-34): the same 512x640 /
+    3-view / S_max 3 adaptive frame shape as 128 x 160 bundles of 16 rays, through whatever path HotPathEngine takes for b = 4
+    (gdb_render_info: the fused entries when they accept the config, else the operator-mirror chain), per step and per RAY against
+    the b = 2 fused step of this run.  tools/bench_b4.py has the per-operator split."""
+    Ho, Wo = 512, 640
+    fr = to_dev(synthetic.make_frame(Ho, Wo, V=3, bundle_size=4, scene="dtu", seed=0), dev)
+    e = HotPathEngine(bundle_size=4, max_num_samples=3, is_adaptive=True, device=dev)
+    e.load_weights(weights_np); e.reuse_outputs = True
+    e.prepare(fr)
+    fused = bool(e.render_info()["fused"])
+    fn = (lambda: (e.prepare(fr), e.render_packed())) if fused else (lambda: (e.prepare(fr), e.render_unfused_packed()))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
+        fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"path": "fused (gdb_render_bundles_packed)" if fused else "operator mirrors (gdb_sample -> gdb_encode -> gdb_mlp -> gdb_composite)",
+            "bundles": e.n_bundles, "rays": Ho * Wo, "ms_per_step": ms, "ns_per_ray": ms * 1e6 / (Ho * Wo), "steps": steps, "precision": "f32",
+            "per_ray_vs_b2_fused_step": (ms * 1e6 / (Ho * Wo)) / fused_ns_per_ray if fused_ns_per_ray else None}
+
+
 def frame_time_ms(dev, precision="f32"):
     """t_frame: whole Network.forward (CNNs on PyTorch-ROCm/MIOpen + the HIP hot path) on DTU eval 512x640, 3 views, random
     init; the reference's protocol (run.py:56-73): synchronise, wall clock, drop the first iterations, mean."""
@@ -377,6 +404,8 @@ def main():
                          "exceed the 256 MiB Infinity Cache, at most 8): consecutive steps then read their inputs from HBM, not from cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary-precision record, PSNR, measured peaks and t_frame")
+    ap.add_argument("--sources-ready-record", action="store_true",
+                    help="with --no-extras: still time the `prepare_sources_ready` record (a sweep of target views over fixed source views)")
     ap.add_argument("--streams", type=int, default=1,
                     help="fused path, N = 1 only: render consecutive (independent) frames on this many HIP streams with their own "
                          "workspaces, so one frame's fill/drain overlaps the next; per-launch durations then overlap too (default 1)")
@@ -661,8 +690,10 @@ def main():
             tj = json.load(open(tpath))
             src_sha = kernel_source_sha16()
             if tj.get("_kernel_source_sha256_16") == src_sha:
-                traffic = tj.get(f"{args.workload}:{kname}:{pname}")
-                tsrc = tj.get("_source")
+                tkey = f"{args.workload}:{kname}:{pname}"
+                traffic = tj.get(tkey)
+                # the file a key's counters were read from (per key since round 6: one generic string named files of OTHER workloads)
+                tsrc = (tj.get("_sources", {}).get(tkey) or tj.get("_source")) if traffic is not None else f"profiles/traffic.json holds no entry for {tkey}"
             else:
                 tsrc = f"profiles/traffic.json was measured on other kernel sources ({tj.get('_kernel_source_sha256_16')} != {src_sha}): refused"
         except Exception:
@@ -688,7 +719,11 @@ def main():
     res = {
         "metric": "rendered rays/sec, GDB-NeRF hot path (sample+fetch+MLP+composite)", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong" if rows_mode else "weak",
+        # `scaling` names how the work of THIS command grows with --gpus (the driver compares the N = 1, 2, 4, 8 lines of one command): with
+        # the default --shard rows ONE frame is split over the ranks (total work fixed: "strong"), with --shard frames every rank renders its
+        # own frame ("weak").  The N = 1 line carries the same word as the N > 1 lines of the same command (it said
+        # "weak" at N = 1 and "strong" at N > 1).
+        "higher_is_better": True, "scaling": "strong" if args.shard == "rows" else "weak",
         "vs_baseline": None, "dtype": DTYPE[pname], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "bundle_size": 2, "rays_per_step": rays_per_step,
                    "path": args.path, "precision": pname, "schedule": args.schedule, "shard": args.shard if world > 1 else "none",
@@ -701,6 +736,41 @@ def main():
         "roofline": roof,
     }
     res.update(extra)
+
+    def sources_ready_record(pname_, k2_):
+        """A sweep of target views over FIXED source views (run.py renders a camera path from one set of source views): the products of
+        k_prepare that depend on the sources alone - the feature pyramid(s), the half-precision image copy - are in the workspace from
+        the sweep's first frame, and every further step rebuilds the camera block and the plan only (GDB_PREP_SOURCES_READY, ABI v7).
+        One engine (workspace) per ring copy of the frame, each prepared in full ONCE, untimed; a step = prepare(sources_unchanged) +
+        render on the next copy.  A second record beside the headline, NEVER the headline: the headline's step prepares in full."""
+        if len(ring_engs) < len(ring):
+            ring_engs.extend(make_engine(ring[i]) for i in range(len(ring_engs), len(ring)))
+        for i_, e_ in enumerate(ring_engs):
+            e_.precision = PREC[pname_]; e_.prepare(ring[i_])
+        kk, pp_ = [0], []
+
+        def step(sample):
+            kk[0] = (kk[0] + 1) % len(ring_engs)
+            e_ = ring_engs[kk[0]]
+            if sample:
+                p0, p1 = events(); p0.record()
+            e_.prepare(ring[kk[0]], sources_unchanged=True)
+            if sample:
+                p1.record(); pp_.append((p0, p1))
+            e_.render(0, H, PREC[pname_], out)
+        timed.rewarm(step, 100.0)
+        dt_ = timed.run(step, 50, k2_)
+        timed.sample(step)
+        for e_ in ring_engs:
+            e_.precision = prec
+        return {"precision": pname_, "value": Ho * Wo * k2_ / dt_, "ms_per_step": dt_ / k2_ * 1e3, "steps": k2_, "prepare_ms": ev_ms(pp_),
+                "vs_headline": (Ho * Wo * k2_ / dt_) / value if pname_ == args.precision else None,
+                "note": "step = gdb_prepare_ex(GDB_PREP_SOURCES_READY) + render: camera block and plan rebuilt, pyramids / image copy of the "
+                        "fixed source views kept; never the headline (its step prepares in full)"}
+
+    if rank == 0 and world == 1 and args.no_extras and args.sources_ready_record and args.path == "fused" and args.streams == 1:
+        res["prepare_sources_ready"] = sources_ready_record(args.precision, max(100, min(args.steps, 1000)))
+        eng.prepare(frame)
 
     if rank == 0 and world == 1 and not args.no_extras and args.path == "fused" and args.streams == 1:
         # Parity in the line itself, against the CPU ORACLE (oracle/gdb_oracle.py, the checker of tests/): the c1-size frame (64x80, BASELINE
@@ -797,9 +867,26 @@ def main():
         res["pipelined_2_streams"] = {"value": Ho * Wo * k2 / dtp, "ms_per_step": dtp / k2 * 1e3, "steps": k2, "precision": args.precision,
                                       "vs_headline": (Ho * Wo * k2 / dtp) / value}
         del e2, o2
+        if args.workload == "c2" and args.precision == "f32":
+            try:
+                res["bundle_size_4"] = b4_record(dev, weights_np, ms_per_step * 1e6 / (Ho * Wo))
+            except Exception as ex:  # measurement extras never take the headline down
+                res["bundle_size_4"] = {"error": repr(ex)}
+        try:
+            res["prepare_sources_ready"] = sources_ready_record(args.precision, k2)
+            if args.precision != "f16":
+                eng.precision = PREC["f16"]
+                res["prepare_sources_ready_f16"] = sources_ready_record("f16", k2)
+                eng.precision = prec
+            eng.prepare(frame)
+        except Exception as ex:  # measurement extras never take the headline down
+            res["prepare_sources_ready"] = {"error": repr(ex)}
         # The same step (prepare + render) replayed from HIP graphs, one captured per ring copy of the frame: the step enqueues on its
         # stream only - no host sync, no allocation (tests/test_hip_parity.py::test_hot_path_step_replays_from_a_hip_graph) - so a sweep
-        # can replay it; the GPU time is the same two kernels, what a replay saves is the host's share of a 0.1 ms step.
+        # can replay it.  What a replay costs (round 6, tools/graph_probe.py -> profiles/r06/graph_probe_f32.json): a FIXED ~5 us of GPU
+        # time per hipGraphLaunch on this ROCm, whatever the graph holds (a one-kernel graph of the render alone: 99.6 us against 94.3
+        # eager; one step per graph 113.7 against 108.6; FOUR steps per graph 110.0) - so the one-step-per-graph record reads ~4 % below
+        # the eager headline and `steps_per_graph_4` closes most of it; the two kernels themselves run as long either way.
         try:
             graphs = []
             side = torch.cuda.Stream(dev)
@@ -821,8 +908,28 @@ def main():
             timed.rewarm(step_graph, 100.0)
             dtg = timed.run(step_graph, 50, k2)
             res["hipgraph_replay"] = {"value": Ho * Wo * k2 / dtg, "ms_per_step": dtg / k2 * 1e3, "steps": k2, "precision": args.precision,
-                                      "graphs": len(graphs), "vs_headline": (Ho * Wo * k2 / dtg) / value}
+                                      "graphs": len(graphs), "vs_headline": (Ho * Wo * k2 / dtg) / value,
+                                      "note": "one step per graph; a hipGraphLaunch costs ~5 us of GPU time whatever it holds (tools/graph_probe.py)"}
             del graphs
+            graphs4 = []
+            for k0 in range(len(ring)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for d in range(4):
+                        eng.prepare(ring[(k0 + d) % len(ring)])
+                        eng.render(0, H, prec, out)
+                graphs4.append(g)
+            g4 = [0]
+
+            def step_graph4(sample):
+                g4[0] = (g4[0] + 4) % len(graphs4)
+                graphs4[g4[0]].replay()
+            timed.rewarm(step_graph4, 100.0)
+            n4 = max(25, k2 // 4)
+            dtg4 = timed.run(step_graph4, 12, n4)
+            res["hipgraph_replay"]["steps_per_graph_4"] = {"value": Ho * Wo * 4 * n4 / dtg4, "ms_per_step": dtg4 / (4 * n4) * 1e3, "steps": 4 * n4,
+                                                           "vs_headline": (Ho * Wo * 4 * n4 / dtg4) / value}
+            del graphs4
             eng.prepare(frame)
         except Exception as ex:  # measurement extras never take the headline down
             res["hipgraph_replay"] = {"error": repr(ex)}

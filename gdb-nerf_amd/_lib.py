@@ -12,13 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # GDB_NERF_LIB selects another build of the same ABI (tools/: the -DGDB_DIAG diagnostic library and A/B flag variants are
 # built beside the product library as libgdbnerf_hip.<tag>.so and never overwrite it).
 LIB_PATH = os.environ.get("GDB_NERF_LIB") or os.path.join(HERE, "libgdbnerf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F16, PREC_F32, PREC_F32X = 0, 1, 2
 SCHED_AUTO, SCHED_SLOT_WAVES, SCHED_SEGMENT_WAVE, SCHED_DENSE, SCHED_FLAT = 0, 1, 2, 3, 4
 SCHED_PLAN_READY = 0x100
 SCHED_PYR16_READY = 0x200
 PREP_PYR16 = 1
 PREP_PYR16_ONLY = 2
+PREP_SOURCES_READY = 4
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8

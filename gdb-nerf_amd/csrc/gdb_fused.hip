@@ -843,6 +843,13 @@ __device__ __forceinline__ void xchg8(unsigned& a0, unsigned& a1, unsigned& a2, 
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
                    "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
 }
+// Offset of mip level l (a per-lane value) among the wave-uniform level offsets, as a SELECT-free sum of masked terms: written as the
+// ternary chain  l == 0 ? 0 : (l == 1 ? lo1 : ...)  hipcc turned each of the chains of a view into divergent branches (s_and_saveexec /
+// s_cbranch_execnz regions around one v_cndmask each - four of them per view in the f16 gather, read off the ISA in round 6).
+__device__ __forceinline__ unsigned level_off(int l, unsigned lo1, unsigned lo2, unsigned lo3) {
+    const unsigned m1 = 0u - (unsigned)(l == 1), m2 = 0u - (unsigned)(l == 2), m3 = 0u - (unsigned)(l >= 3);
+    return (lo1 & m1) | (lo2 & m2) | (lo3 & m3);
+}
 // GDB_PREC_F32 / F32X: the feature taps come from the fp32 pyramid, the colours from the planar fp32 source images.
 // The bilinear taps of the two mip levels are computed ONCE per sample (round 5): lane half 0 forms level l0's byte offsets and weights,
 // half 1 level l1's (the same instructions on per-lane level data), and v_permlane32_swap hands each half the other's - 16 + 2
@@ -888,7 +895,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     Taps t0, t1;
     {
         const int lm = h ? l1 : l0;
-        const unsigned om = lm == 0 ? 0u : (lm == 1 ? lo1 : (lm == 2 ? lo2 : lo3));
+        const unsigned om = lm == 0 ? 0u : (lm == 1 ? lo1 : (lm == 2 ? lo2 : lo3));   // (ONE chain per view here; as level_off() the split-f16 flat build spills four scalar registers)
         const Taps m = make_taps(tu, tvv, f.W >> lm, f.H >> lm, om << 2, h ? frac : 1.f - frac);
         unsigned a0 = m.o00, a1 = m.o10, a2 = m.o01, a3 = m.o11, b0 = a0, b1 = a1, b2 = a2, b3 = a3;
         float a4 = m.w00, a5 = m.w10, a6 = m.w01, a7 = m.w11, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
@@ -1053,8 +1060,8 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
         t0.p00 = a0; t0.p10 = a1; t0.p01 = a2; t0.p11 = a3; t0.edge = a4; t0.w00 = a5; t0.w10 = a6; t0.w01 = a7; t0.w11 = a8;
         t1.p00 = b0; t1.p10 = b1; t1.p01 = b2; t1.p11 = b3; t1.edge = b4; t1.w00 = b5; t1.w10 = b6; t1.w01 = b7; t1.w11 = b8;
     }
-    const unsigned o0 = 2u * (l0 == 0 ? 0u : (l0 == 1 ? lo1 : (l0 == 2 ? lo2 : lo3))), hw0 = __umul24(f.W >> l0, f.H >> l0);
-    const unsigned o1 = 2u * (l1 == 0 ? 0u : (l1 == 1 ? lo1 : (l1 == 2 ? lo2 : lo3))), hw1 = __umul24(f.W >> l1, f.H >> l1);
+    const unsigned o0 = 2u * level_off(l0, lo1, lo2, lo3), hw0 = __umul24(f.W >> l0, f.H >> l0);
+    const unsigned o1 = 2u * level_off(l1, lo1, lo2, lo3), hw1 = __umul24(f.W >> l1, f.H >> l1);
     RgbTaps rt[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337

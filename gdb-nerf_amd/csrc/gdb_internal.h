@@ -103,8 +103,14 @@ struct WsLayout {
 
 #define SCAN_BLOCK 1024
 // flat schedule: floats per (sample, lane half) record of a straddling bundle: 20 pre-weight values (16 blended + 4 feat_head),
-// alpha, the depth term; padded to 24
-#define FLAT_REC 24
+// alpha, the depth term, the boundary's header (map index, sample count) = 24 floats, padded to 32: ONE 128-byte line per record
+// (the region is 256-byte aligned), so that no line of the side buffer is shared between two records - i.e. between two lanes, two
+// waves or two window boundaries: a line is written by one lane (six 16-byte write-through stores) and read by one wave (the last
+// arriver of its boundary), once per launch each, the read after the write has drained (at 96 bytes a
+// record shared its lines with the next boundary's, which another wave may have pulled into its L2 before they were written)
+#ifndef FLAT_REC
+#define FLAT_REC 32
+#endif
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Fixed sample counts (is_adaptive = 0) for which GDB_SCHED_AUTO takes the DENSE schedule at fp32 / split-f16 (the sample list is then

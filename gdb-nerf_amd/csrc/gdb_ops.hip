@@ -567,7 +567,7 @@ extern "C" int gdb_prepare(const GdbConfig* cfg, const GdbFrame* f, void* ws, si
 }
 
 extern "C" int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, int32_t flags, void* ws, size_t ws_bytes, void* stream_) {
-    if (flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: unknown flag bits 0x%x", (unsigned)(flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)));
+    if (flags & ~GDB_PREP_ALL) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: unknown flag bits 0x%x", (unsigned)(flags & ~GDB_PREP_ALL));
     if ((flags & GDB_PREP_PYR16_ONLY) && !(flags & GDB_PREP_PYR16)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex: GDB_PREP_PYR16_ONLY needs GDB_PREP_PYR16");
     if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_ex with d_fpn_feat resamples frame->d_src_images: it is NULL");
     return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_);
@@ -578,7 +578,7 @@ extern "C" int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* f, const flo
 // item only.
 extern "C" int gdb_prepare_rows(const GdbConfig* cfg, const GdbFrame* f, const float* d_fpn_feat, int32_t flags, int32_t row_begin, int32_t row_end,
                                 void* ws, size_t ws_bytes, void* stream_) {
-    if (flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: unknown flag bits 0x%x", (unsigned)(flags & ~(GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY)));
+    if (flags & ~GDB_PREP_ALL) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: unknown flag bits 0x%x", (unsigned)(flags & ~GDB_PREP_ALL));
     if ((flags & GDB_PREP_PYR16_ONLY) && !(flags & GDB_PREP_PYR16)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: GDB_PREP_PYR16_ONLY needs GDB_PREP_PYR16");
     if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows with d_fpn_feat resamples frame->d_src_images: it is NULL");
     if (row_end < 0) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) is negative", row_begin, row_end);
@@ -607,6 +607,15 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     if (a.levels > 3) return gdb_fail(GDB_E_BADARG, "max_mipmap_level > 3 unsupported by the tile kernel");
     a.tilesX = (f->W + PT_W - 1) / PT_W; a.tilesY = (f->H + PT_H - 1) / PT_H;
     a.ntiles = (f->d_img_feat || fpn_feat) ? a.tilesX * a.tilesY * f->B * f->V : 0;
+    // GDB_PREP_PYR16 with a feature map also copies the source images to half precision (the GDB_PREC_F16 kernels read their colour
+    // taps from that copy): without them a later f16 render told GDB_SCHED_PYR16_READY would read uninitialised workspace
+    if ((flags & GDB_PREP_PYR16) && a.ntiles && !f->d_src_images)
+        return gdb_fail(GDB_E_BADARG, "GDB_PREP_PYR16 copies frame->d_src_images to half precision beside the pyramid: it is NULL");
+    // GDB_PREP_SOURCES_READY (ABI v7): the caller vouches that the products that depend on the SOURCE views alone - the feature pyramid(s)
+    // and the half-precision image copy the other flags name - are in this workspace from an earlier prepare of the same source tensors,
+    // contents unchanged: only the camera block and the plan are rebuilt (a sweep of target views over fixed source views).
+    const bool sources_ready = (flags & GDB_PREP_SOURCES_READY) != 0;
+    if (sources_ready) a.ntiles = 0;
     a.b = cfg->bundle_size; a.inv_depth = cfg->inv_depth; a.gnd = cfg->global_num_depth;
     for (int i = 0; i <= GDB_MAX_MIP; ++i) { a.lvlH[i] = L.lvlH[i]; a.lvlW[i] = L.lvlW[i]; a.lvlOff[i] = (unsigned)L.lvlOff[i]; }
     a.pyrStride = (unsigned)L.pyrStride;
@@ -632,7 +641,9 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     a.plan_r0 = row_begin; a.plan_nr = row_end - row_begin;
     a.nplan = (f->d_depth_range && a.plan_nr > 0 && (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, f->V))) ? (f->B * a.plan_nr + 3) / 4 : 0;
     // the half-precision RGBA copy of the source images rides in the same launch, behind the pyramid tiles
-    a.img16 = (a.pyr16 && f->d_src_images && a.ntiles) ? (char*)ws + L.img16Off : nullptr;
+    // (the copy is made of x PAIRS of pixels, for the fused kernels, which are built for bundle_size 2: an even pixel count; other
+    // configs - the operator mirrors' - never read it)
+    a.img16 = (a.pyr16 && f->d_src_images && a.ntiles && cfg->bundle_size == 2 && (((size_t)f->Ho * f->Wo) & 1) == 0) ? (char*)ws + L.img16Off : nullptr;
     a.nimg = a.img16 ? (int)(((size_t)f->B * f->V * f->Ho * f->Wo / 2 + 255) / 256) : 0;
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan + a.nimg), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");

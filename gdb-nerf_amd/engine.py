@@ -163,14 +163,19 @@ class HotPathEngine:
 
     # ---- per-frame preparation -----------------------------------------------------------
     @_on_device
-    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None, rows=None) -> Optional[int]:
+    def prepare(self, frame: Dict[str, torch.Tensor], im_size=None, rows=None, sources_unchanged: bool = False) -> Optional[int]:
         """Validate shapes on the host, then build the camera block and the feature pyramid.  A frame
         without the source side (only tar_ext, tar_int, near_far [, depth_range, vol_range]; pass
         `im_size=(Ho,Wo)`) prepares the target camera alone — enough for build_rays / sample.
         Returns the number of mip levels built beyond level 0 (None without the source side); it is below
         `max_mipmap_level` when an extent of the feature map turns odd on the way down (warned once).
         rows = (r0, r1): this engine will render the bundle-map rows [r0, r1) only (a rank's strip, `parallel.row_strip`): the list
-        schedules' plan is built for those rows alone (gdb_prepare_rows); a render outside them rebuilds the plan itself."""
+        schedules' plan is built for those rows alone (gdb_prepare_rows); a render outside them rebuilds the plan itself.
+        sources_unchanged = True: the caller vouches that `src_images` and `img_feat` / `fpn_feat` are the tensors - same storage, same
+        contents - of this engine's previous prepare() (a sweep of target views over fixed source views): the feature pyramid(s) and the
+        half-precision image copy in the workspace are kept (GDB_PREP_SOURCES_READY, ABI v7), the camera block and the plan are rebuilt.
+        Ignored (a full prepare runs) when the workspace holds no such products: first call, another frame shape, another precision's
+        products, or other storage pointers than last time."""
         b = self.b
         if "src_images" in frame:
             si = frame["src_images"]
@@ -229,6 +234,13 @@ class HotPathEngine:
         flags = _lib.PREP_PYR16 if (self.precision == _lib.PREC_F16 and "src_images" in frame) else 0
         if flags and self.f16_only_prepare:
             flags |= _lib.PREP_PYR16_ONLY
+        # what the source-only products in the workspace were built from: shape, flags, storage pointers (contents are the caller's promise)
+        src_key = None
+        if "src_images" in frame:
+            src_key = (dims, flags, frame["src_images"].data_ptr(), (fpn if fpn is not None else frame["img_feat"]).data_ptr(), self._ws.data_ptr())
+        if sources_unchanged and src_key is not None and src_key == getattr(self, "_src_key", None):
+            flags |= _lib.PREP_SOURCES_READY
+        self._src_key = None   # armed again once the launch below has been accepted
         self._plan_rows = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
         if rows is None:
             _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags,
@@ -236,6 +248,7 @@ class HotPathEngine:
         else:
             _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
                                                  self._ws.data_ptr(), self._ws.numel(), self._stream()))
+        self._src_key = src_key
         self._pyr16_ready = bool(flags & _lib.PREP_PYR16)
         self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
@@ -272,6 +285,7 @@ class HotPathEngine:
         _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(self._frame), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
                                              self._ws.data_ptr(), self._ws.numel(), self._stream()))
         self._pyr32_ready = True
+        self._src_key = None   # (the workspace now holds other products than the key describes: the next prepare() runs in full)
 
     @staticmethod
     def _prior_key(dr: Optional[torch.Tensor]):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GDB_ABI_VERSION 6
+#define GDB_ABI_VERSION 7
 
 typedef enum GdbStatus {
     GDB_OK = 0,
@@ -153,9 +153,25 @@ int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_
  *   GDB_PREP_PYR16_ONLY  (with GDB_PREP_PYR16) write ONLY the half-precision pyramid: the fp32 pyramid in the workspace is left as
  *                   it was (26 of the 58 MB k_prepare moves at 512x640, V = 3).  Only GDB_PREC_F16 fused renders may follow; gdb_encode, the
  *                   f32 / split-f16 renders and gdb_build_pyr16 read the fp32 pyramid and need a prepare without this flag first
- *                   (like GDB_SCHED_PLAN_READY this is the caller's promise: the library keeps no state to check it against). */
+ *                   (like GDB_SCHED_PLAN_READY this is the caller's promise: the library keeps no state to check it against).
+ *   (GDB_PREP_PYR16, in full: besides the pyramid it writes a HALF-PRECISION RGBA COPY OF frame->d_src_images behind it - 8 bytes per
+ *                   pixel, halves (r, g, b, 0) - from which the GDB_PREC_F16 kernels read their colour taps (one 16-byte load per x pair of a
+ *                   tap row).  So with this flag the colours a later f16 render sees are those of d_src_images AT THIS CALL:
+ *                   GDB_SCHED_PYR16_READY is the promise that neither d_img_feat / d_fpn_feat nor d_src_images have changed since.
+ *                   A frame that carries a feature map but no d_src_images is refused with this flag (GDB_E_BADARG).  The copy is made
+ *                   for bundle_size 2 (the fused kernels' size) only; gdb_pyramid16_layout does not describe it: it starts at the
+ *                   first 256-byte boundary behind the B * V pyramid blocks + 16 bytes of padding.)
+ *   GDB_PREP_SOURCES_READY  (ABI v7) the caller vouches that everything in the workspace that depends on the SOURCE views alone - the fp32
+ *                   pyramid, and with GDB_PREP_PYR16 the half-precision pyramid and image copy - was built by an earlier gdb_prepare*
+ *                   call on this workspace, with the same flags, from d_img_feat / d_fpn_feat / d_src_images whose contents have not
+ *                   changed: this call rebuilds the camera block (target AND source records) and the list schedules' plan only - what
+ *                   a sweep of target views over fixed source views needs per view (bundle_sampler.py:304-313 recomputes the camera
+ *                   terms per call; nvdiffrast rebuilds the mip stack per call, :355-359 - this flag is where this library does not).
+ *                   Like the two render-side promises the library keeps no state to check it against. */
 #define GDB_PREP_PYR16 1
 #define GDB_PREP_PYR16_ONLY 2
+#define GDB_PREP_SOURCES_READY 4
+#define GDB_PREP_ALL (GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY | GDB_PREP_SOURCES_READY)
 int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, void* d_workspace,
                    size_t workspace_bytes, void* stream);
 

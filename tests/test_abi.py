@@ -48,8 +48,9 @@ def test_workspace_bytes_and_errors(lib):
     pyr = 3 * 20 * 4 * (256 * 320 + 128 * 160 + 64 * 80 + 32 * 40)
     # camera block + pyramid + its half-precision copy (GDB_PREC_F16's taps) + per-bundle counts / offsets (mirror) + dense plan +
     # sample list (4 B per sample offset of a row)
-    # ... and the flat schedule's straddling-bundle records: (81920 x 3 / 32 + 3) boundaries x 3 samples x 2 lane halves x 24 floats, + headers
-    flat = (256 * 320 * 3 // 32 + 3) * (3 * 2 * 24 * 4 + 8)
+    # ... and the flat schedule's straddling-bundle records: (81920 x 3 / 32 + 3) boundaries x 3 samples x 2 lane halves x 32 floats
+    # (one 128-byte line per record since round 6), + headers
+    flat = (256 * 320 * 3 // 32 + 3) * (3 * 2 * 32 * 4 + 8)
     # ... and the half-precision RGBA copy of the source images (GDB_PREC_F16's colour taps): 8 bytes per pixel and view
     img16 = 3 * 512 * 640 * 8
     assert pyr + pyr // 2 + img16 < n.value < pyr + pyr // 2 + img16 + 2 * 256 * 320 * 4 + 256 * (32 * 30 + 32) * 4 + flat + 96 * 1024
@@ -131,7 +132,7 @@ int main(void) {
     GdbConfig c; GdbFrame f;
     if (sizeof(GdbConfig) != 40 || sizeof(GdbFrame) != 112 || offsetof(GdbFrame, d_src_images) != 32) return 10;
     for (i = 0; i < sizeof fns / sizeof fns[0]; ++i) if (!fns[i]) return 11;
-    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 6) return 12;
+    if (gdb_abi_version() != GDB_ABI_VERSION || GDB_ABI_VERSION != 7) return 12;
     memset(&c, 0, sizeof c); memset(&f, 0, sizeof f);
     c.bundle_size = 3; c.max_num_samples = 3; c.global_num_depth = 64; c.feat_dim = 16; c.voxel_dim = 8; c.hid_dim = 64;
     if (gdb_packed_weight_floats(&c, &n) != GDB_E_BADARG) return 13;            /* bundle size must be a power of 2 */

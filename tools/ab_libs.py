@@ -5,6 +5,8 @@ build of libgdbnerf_hip (the product library and `libgdbnerf_hip.<tag>.so` varia
 through GDB_NERF_LIB).  The builds are interleaved over REPS rounds so that clock drift of the box hits all of them alike.
 
     python tools/ab_libs.py --libs base,product --cases c2:f32:1,c2:f32:3,c4:f32:0 [--steps 300] [--reps 3]
+
+A workload name may carry an S_max / sampling override: `c2@6f` = the c2 frame at S_max 6 with fixed counts, `c2@8a` = S_max 8 adaptive.
 """
 import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,9 +44,13 @@ def child(cases, steps):
     frames = {}
     for case in cases:
         wl_name, prec, sched = case.split(":")
-        wl = WORKLOADS[wl_name]
-        if wl_name not in frames:
-            frames[wl_name] = to_dev(synthetic.make_frame(wl["Ho"], wl["Wo"], V=wl["V"], scene=wl["scene"], seed=0), dev)
+        base_name, _, ovr = wl_name.partition("@")
+        wl = dict(WORKLOADS[base_name])
+        if ovr:
+            wl["S"], wl["adaptive"] = int(ovr[:-1]), ovr[-1] == "a"
+        if base_name not in frames:
+            frames[base_name] = to_dev(synthetic.make_frame(wl["Ho"], wl["Wo"], V=wl["V"], scene=wl["scene"], seed=0), dev)
+        frames[wl_name] = frames[base_name]
         eng = HotPathEngine(max_num_samples=wl["S"], is_adaptive=wl["adaptive"], device=dev)
         eng.set_schedule(int(sched)); eng.precision = PREC[prec]; eng.load_weights(w)
         eng.prepare(frames[wl_name])
