@@ -20,6 +20,8 @@ SCHED_PYR16_READY = 0x200
 PREP_PYR16 = 1
 PREP_PYR16_ONLY = 2
 PREP_SOURCES_READY = 4
+PREP_STRIP_REACH = 8
+PREP_STRIP_WHOLE = 16
 
 GDB_OK, GDB_E_BADARG, GDB_E_SHAPE, GDB_E_HIP, GDB_E_WORKSPACE = 0, -1, -2, -3, -4
 GDB_MAX_SAMPLES, GDB_MAX_MIP, GDB_MAX_VIEWS = 16, 3, 8

@@ -438,6 +438,7 @@ struct FusedArgs {
     int row_lo, row_hi, tile_stride;  // dense schedule: global rows (batch item x H + row) of this launch; tiles a wave skips per step
     int flat_base;    // flat schedule: index of this launch's first window boundary in the side buffers (one launch per batch item)
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
+    float* wv;        // bundle_size 1 / 4 only: per (bundle, sample slot, view) the colour weight k_bundle_colours applies (else NULL)
     unsigned* dbg;    // diagnostic build only
 };
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte store to a 4-byte aligned address (gfx950: dword alignment suffices)
@@ -854,6 +855,9 @@ __device__ __forceinline__ unsigned level_off(int l, unsigned lo1, unsigned lo2,
 // The bilinear taps of the two mip levels are computed ONCE per sample (round 5): lane half 0 forms level l0's byte offsets and weights,
 // half 1 level l1's (the same instructions on per-lane level data), and v_permlane32_swap hands each half the other's - 16 + 2
 // instructions against make_taps' ~86 a second time.  On the fp32 datapath a vector instruction is matrix time.
+// RGB = false (bundle_size 1 / 4, round 6): the sub-ray colours are not gathered here - a lane half owns two sub-rays of a 2 x 2 bundle,
+// not b^2 / 2 of any bundle - but by k_bundle_colours afterwards, from the blend weights this kernel leaves per (sample, view).
+template <bool RGB = true>
 __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                             float ball, const float td[3], float4 feat[3], float dir[4], float rgb[2][3], int skip) {
 #pragma clang fp contract(off)   // (every fused multiply-add below is written fmaf: see tex_coord_f)
@@ -865,7 +869,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
         for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
     }
     const float* img = f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo;
-    const bool do_rgb = !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
+    const bool do_rgb = RGB && !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
     // ---- addresses and weights --------------------------------------------------------------------
     // sphere centre in the camera frame: the mean of the sub-ray points maps to the mean of their images   :340
     float cc[3];
@@ -906,6 +910,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
     }
     const bool two = frac > 0.f && do_tex;
     RgbTaps rt[2];
+    if constexpr (RGB) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
         float im[3];  // K (E x + t) as one pre-multiplied 3x4 (S_P): 9 FMAs per point instead of 18
@@ -914,6 +919,7 @@ __device__ __forceinline__ void gather_view(const DevFrame& f, int bi, int v, in
             im[r] = fmaf(sc[S_P + 4 * r], xyz[e][0], fmaf(sc[S_P + 4 * r + 1], xyz[e][1], fmaf(sc[S_P + 4 * r + 2], xyz[e][2], sc[S_P + 4 * r + 3])));
         float iz = frcp(fmaxf(im[2], 1e-6f));
         rt[e] = rgb_taps(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
+    }
     }
     // ---- issue: level 0 and both sub-rays' colours in flight together -------------------------------
     TapData d0, d1;
@@ -1014,6 +1020,7 @@ __device__ __forceinline__ void rgb_combine16(const RgbTaps& t, const RgbData16&
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgb[c] = fmaf((float)d.b[4 + c], t.w11, fmaf((float)d.b[c], t.w01, fmaf((float)d.a[4 + c], t.w10, (float)d.a[c] * t.w00)));
 }
+template <bool RGB = true>
 __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, int h, const float xyz[2][3], const float ctr[3],
                                               float ball, const float td[3], float4 feat[3], float dir[4], float rgb[2][3], int skip) {
 #pragma clang fp contract(off)   // (every fused multiply-add below is written fmaf: see tex_coord_f)
@@ -1024,7 +1031,7 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
 #pragma unroll
         for (int i = 0; i < SRC_STRIDE; ++i) sc[i] = scg[i];
     }
-    const bool do_rgb = !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
+    const bool do_rgb = RGB && !SKIPPED(skip, 1), do_tex = !SKIPPED(skip, 2);
     // ---- footprint -> mip level, texture coordinates (as gather_view)   bundle_sampler.py:340-353 -----------------------------------
     float cc[3];
 #pragma unroll
@@ -1063,6 +1070,7 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
     const unsigned o0 = 2u * level_off(l0, lo1, lo2, lo3), hw0 = __umul24(f.W >> l0, f.H >> l0);
     const unsigned o1 = 2u * level_off(l1, lo1, lo2, lo3), hw1 = __umul24(f.W >> l1, f.H >> l1);
     RgbTaps rt[2];
+    if constexpr (RGB) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // this half's two sub-rays   :327-337
         float im[3];
@@ -1071,6 +1079,7 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
             im[r] = fmaf(sc[S_P + 4 * r], xyz[e][0], fmaf(sc[S_P + 4 * r + 1], xyz[e][1], fmaf(sc[S_P + 4 * r + 2], xyz[e][2], sc[S_P + 4 * r + 3])));
         float iz = frcp(fmaxf(im[2], 1e-6f));
         rt[e] = rgb_taps16(f.Ho, f.Wo, im[0] * iz, im[1] * iz);
+    }
     }
     // ---- issue: level 0 and both sub-rays' colours in flight together (6 + 4 loads) ---------------------------------------------
     // (Measured, round 5 - profiles/r05/ab_f16_both_levels_in_flight.txt: level 1 fetched unconditionally - its products are exact zeros
@@ -1094,13 +1103,17 @@ __device__ __forceinline__ void gather_view16(const DevFrame& f, int bi, int v, 
 // false (and writes an empty composite record) when no lane has a sample in this slot.
 // Sample slot k of the bundle q (already loaded) for this lane: the views' contributions go to the wave's staging area.
 // vox[i] = voxel-feature channel 4h + i of this lane's sample.
-template <int PREC>
-__device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, const float* __restrict__ tc, const Bundle<4>& q, int k, int bi,
+// BB = 4: a 2 x 2 bundle (the sub-ray colours gathered here, two sub-rays per lane half); BB = 1: the bundle's CENTRE ray alone
+// (load_bundle_center: bundle_size 1 / 4, whose colours k_bundle_colours gathers afterwards).
+template <int PREC, int BB = 4>
+__device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, const float* __restrict__ tc, const Bundle<BB>& q, int k, int bi,
                                               int j, int h, int skip, bool act, float& z, float vox[4]) {
 #pragma clang fp contract(off)   // (the voxel taps' coordinates and weights: see tex_coord_f; the tap sums below are written fmaf)
+    static_assert(BB == 4 || BB == 1, "a 2 x 2 bundle, or the centre ray of any other");
+    constexpr bool RGB = BB == 4;
     const int V = f.V;
-    float dn, ball, xyz[4][3], ctr[3];
-    bundle_sample<4, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
+    float dn, ball, xyz[BB][3], ctr[3];
+    bundle_sample<BB, true>(f, q, min(k, q.count - 1), z, dn, xyz, ctr, ball);  // bundle_sampler.py:246-263
 
     // Lanes WITHOUT a sample in this slot gather too (round 5): their bundle and slot are clamped to a real sample of the window (its
     // coordinates are as valid as any lane's), so the whole gather is straight-line code - no exec-masked region, no zero-initialised
@@ -1148,7 +1161,7 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) xyzh[e][r] = h ? xyz[2 + e][r] : xyz[e][r];
+        for (int r = 0; r < 3; ++r) xyzh[e][r] = RGB ? (h ? xyz[(2 + e) % BB][r] : xyz[e % BB][r]) : 0.f;
 
     float td[3];
     target_dir(ctr, tc + T_O, td);
@@ -1156,10 +1169,10 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
         float* st = stage + (size_t)v * stage_v<PREC>();
         float4 feat[3];
         float dir[4], rgb[2][3];
-        if constexpr (PREC == GDB_PREC_F16) gather_view16(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
-        else if constexpr (PREC == GDB_PREC_F32) gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        if constexpr (PREC == GDB_PREC_F16) gather_view16<RGB>(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+        else if constexpr (PREC == GDB_PREC_F32) gather_view<RGB>(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
         else {   // split-f16 at three waves per SIMD has no register for the straight-line form (it spills one): lanes without a sample skip
-            if (act) gather_view(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
+            if (act) gather_view<RGB>(f, bi, v, h, xyzh, ctr, ball, td, feat, dir, rgb, skip);
             else {
                 const float u = __builtin_nondeterministic_value(0.f);
                 feat[0] = feat[1] = feat[2] = make_float4(u, u, u, u);
@@ -1172,6 +1185,7 @@ __device__ __forceinline__ void slot_gather_q(const DevFrame& f, float* stage, c
             }
         }
         constexpr int RF = row_feat<PREC>(), RD = row_dir<PREC>();
+        // (RGB = false: the colour rows are written all the same - zeros - so that the blend pass of the MLP core reads finite values)
         if constexpr (PREC == GDB_PREC_F16) {  // colours as packed halves: row 2c + h = (sub-ray 2h, 2h + 1) of colour c
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             unsigned* su = (unsigned*)st;
@@ -2353,7 +2367,9 @@ __device__ __forceinline__ void flat_fix_boundary(const FusedArgs& a, const DevF
 // records are in memory (their wave drained its write-through stores before its add) and the loads of flat_fix_boundary go past this
 // CU's L1 (sc1); it composites the bundle and returns the counter to zero for the next render.  pend: bit 0 = arrived at boundary b
 // (lane 0 holds that ticket), bit 1 = at boundary b + 1 (lane 1).  GDB_FLAT_ACQUIRE adds the agent-scope acquire of the guide's general
-// recipe (buffer_inv sc1: every wave of the CU then refills its L1); measured beside the default: DESIGN.md.
+// recipe (buffer_inv sc1: every wave of the CU then refills its L1): +4.7 .. 11 us per launch (profiles/r06/
+// ab_flat_record_128B_and_acquire.txt), so it is a build switch and the default rests on one 128-byte line per side record instead -
+// DESIGN.md 4.2b, "What the hand-off's memory ordering rests on".
 __device__ __forceinline__ void flat_settle(const FusedArgs& a, const DevFrame& f, int ticket, int pend, int b, int lane) {
     const bool last_h = (pend & 1) && __builtin_amdgcn_readlane(ticket, 0) == 1, last_t = (pend & 2) && __builtin_amdgcn_readlane(ticket, 1) == 1;
     if (!(last_h | last_t)) return;
@@ -2378,8 +2394,14 @@ __device__ __forceinline__ void flat_settle(const FusedArgs& a, const DevFrame& 
 // and a wave renders at most ONE tile - then nothing has to be kept out of the tile loop's way and the kernel arguments are plain
 // loop-free SGPR values again.  GDB_SCHED_AUTO always walks (profiles/r04/ab_walk_vs_one_tile.txt); the one-tile form is what the
 // split-f16 flat build at three waves per SIMD takes (no register left for the walk's loop state) and a diagnostic switch.
-template <int PREC, int NWG, bool PERSIST, bool FLAT>
+// BB = 4: bundle_size 2, everything in this launch.  BB = 1 (dense only; round 6): bundle_size 1 / 4 - the list kernel renders the bundle's
+// CENTRE ray (everything of a sample but its 3 b^2 sub-ray colours: the MLP never sees those, nerf.py:98 slices them off) into packed
+// rows of the b = 2 shape and leaves, per (sample, view), the weight its colours get in the bundle's output - normalised composite
+// weight (utils.py:35-41) x softmax blend weight (nerf.py:108-110); k_bundle_colours (below) then gathers the b^2 colours per sample and
+// view with those weights and assembles the (N_b, 3 b^2 + 27 [+ 2]) rows.
+template <int PREC, int NWG, bool PERSIST, bool FLAT, int BB = 4>
 __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
+    static_assert(BB == 4 || (BB == 1 && !FLAT && PREC != GDB_PREC_F32X), "the centre-ray form exists for the dense schedule at fp32 / f16 operands");
     // Everything wave-uniform is re-derived inside each tile iteration from an opaque pointer to the kernel-argument segment (as in
     // k_render_solo): as loop invariants those values would be live across the whole body, which has no register to spare.
     typedef const FusedArgs __attribute__((address_space(4))) KArgs;
@@ -2518,11 +2540,12 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
     float vox[4];
     {
         float z_g;
-        Bundle<4> q;
-        load_bundle<4, true, false>(f, tc, bi, row_l, mx, q);
+        Bundle<BB> q;
+        if constexpr (BB == 4) load_bundle<4, true, false>(f, tc, bi, row_l, mx, q);
+        else load_bundle_center<false>(f, tc, bi, row_l, mx, q);
         q.count = min(max(mcnt, 1), f.S_max);  // the plan's count (bundle_sampler.py:179 evaluated by plan_row): no second IEEE division per lane
         STAMP(1);
-        slot_gather_q<PREC>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
+        slot_gather_q<PREC, BB>(f, stage, tc, q, min(k_g, q.count - 1), bi, j, h, a.skip, act, z_g, vox);
     }
     STAMP(2);
     wave_prio<PERSIST && !FLAT>(it + 1 >= ntile, false);
@@ -2576,6 +2599,7 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
         }
     }
     const int S = f.S_max;
+    float w_own = 0.f;   // this sample's transmittance weight alpha x T (utils.py:35), before the bundle's normalisation
     if (S <= 4) {
         // An active sample's earlier samples are the lanes just below it in the same half (k <= j), a bundle's later samples the
         // lanes just above (they end at lane 31 at the latest): whole-wave DPP shifts never carry a value across a bundle's edge
@@ -2587,6 +2611,7 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
             if (d <= k) Tr *= 1.f - ap_;
         }
         const float w = al * Tr;
+        w_own = w;
 #pragma unroll
         for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;  // lanes without a sample hold unspecified MLP outputs
         v[20] = w;
@@ -2616,6 +2641,7 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
             if (d <= k) Tr *= 1.f - ap_;
         }
         const float w = al * Tr;
+        w_own = w;
 #pragma unroll
         for (int i = 0; i < 20; ++i) v[i] = act ? w * v[i] : 0.f;
         v[20] = w;
@@ -2627,6 +2653,23 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
                 const float tt = __shfl_down(v[i], d, 32);
                 if (take) v[i] += tt;
             }
+        }
+    }
+    if constexpr (BB != 4) {
+        // ---- bundle_size 1 / 4: the weight this sample's colours of view v get in the bundle's output (k_bundle_colours) ----------------
+        // = w / max(sum over the bundle, 1e-6) (utils.py:38-41; the bundle's first lane holds the sum) x exp(logit_v - max) / sum_v (nerf.py:
+        // 109-110: the logits lie in the first direction row of each staged view, where the blend pass left them; the same exp / reciprocal
+        // the pass itself took).  Written by lane half 0 of every lane that carries a sample; slots past a bundle's count are never read.
+        constexpr int RD = row_dir<PREC>(), SV = stage_v<PREC>();
+        const float wsum = __shfl(v[20], (h << 5) | max(j - k, 0));
+        const float wn = w_own * (1.f / fmaxf(wsum, 1e-6f));
+        float mxl = -INFINITY, den = 0.f;
+        for (int vv = 0; vv < f.V; ++vv) mxl = fmaxf(mxl, stage[(size_t)vv * SV + RD * 32 + j]);
+        for (int vv = 0; vv < f.V; ++vv) den += __expf(stage[(size_t)vv * SV + RD * 32 + j] - mxl);
+        const float rdn = frcp(den);
+        if (act && h == 0) {
+            float* wp = a.wv + (((size_t)bi * f.H * f.W + (size_t)gb) * f.S_max + k) * f.V;
+            for (int vv = 0; vv < f.V; ++vv) wp[vv] = wn * (__expf(stage[(size_t)vv * SV + RD * 32 + j] - mxl) * rdn);
         }
     }
     STAMP(7);
@@ -2676,8 +2719,8 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
     }
 }
 
-template <int PREC, int WPS, int NWG, bool PERSIST>
-__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) { render_list_body<PREC, NWG, PERSIST, false>(a_); }
+template <int PREC, int WPS, int NWG, bool PERSIST, int BB = 4>
+__global__ void __launch_bounds__(64 * NWG, WPS) k_render_dense(FusedArgs a_) { render_list_body<PREC, NWG, PERSIST, false, BB>(a_); }
 template <int PREC, int WPS, int NWG, bool PERSIST>
 __global__ void __launch_bounds__(64 * NWG, WPS) k_render_flat(FusedArgs a_) { render_list_body<PREC, NWG, PERSIST, true>(a_); }
 
@@ -2738,18 +2781,18 @@ static hipError_t resident_workgroups(K kernel, int threads, size_t lds, std::at
     return hipSuccess;
 }
 
-template <int PREC, int WPS, int NWG>
+template <int PREC, int WPS, int NWG, int BB = 4>
 static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
     static std::atomic<unsigned long long> done{0}, done1{0};
     static std::atomic<unsigned long long> resident[64];
-    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG, true>, done);
+    hipError_t e = allow_big_lds(k_render_dense<PREC, WPS, NWG, true, BB>, done);
 #ifdef GDB_DIAG   // (the one-tile-per-wave form exists in the diagnostic build only: GDB_SCHED_AUTO always walks)
-    if (e == hipSuccess) e = allow_big_lds(k_render_dense<PREC, WPS, NWG, false>, done1);
+    if constexpr (BB == 4) if (e == hipSuccess) e = allow_big_lds(k_render_dense<PREC, WPS, NWG, false>, done1);
 #endif
     (void)done1;
     if (e != hipSuccess) return e;
     int per_cu = 1, cus = 1;
-    e = resident_workgroups(k_render_dense<PREC, WPS, NWG, true>, 64 * NWG, NWG * lds, resident, per_cu, cus);
+    e = resident_workgroups(k_render_dense<PREC, WPS, NWG, true, BB>, 64 * NWG, NWG * lds, resident, per_cu, cus);
     if (e != hipSuccess) return e;
 #ifdef GDB_DIAG  // diagnostic build: over- / under-subscribe the persistent grid (workgroups per CU) from the environment
     static const int env_wgs = getenv("GDB_DENSE_WGS_PER_CU") ? atoi(getenv("GDB_DENSE_WGS_PER_CU")) : 0;
@@ -2784,15 +2827,15 @@ static hipError_t launch_dense_n(FusedArgs& a, size_t lds, hipStream_t st) {
         bool persist = true;
 #ifdef GDB_DIAG
         static const int env_persist = getenv("GDB_DENSE_PERSIST") ? atoi(getenv("GDB_DENSE_PERSIST")) : -1;
-        if (env_persist >= 0) persist = env_persist != 0;
+        if (env_persist >= 0 && BB == 4) persist = env_persist != 0;
 #endif
         if (!persist) g = worst;
         a.tile_stride = (int)(g >> 3) * NWG;
 #ifdef GDB_DIAG
-        if (!persist) hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        if (!persist && BB == 4) hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, false>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         else
 #endif
-        hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, true>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
+        hipLaunchKernelGGL((k_render_dense<PREC, WPS, NWG, true, BB>), dim3((unsigned)g), dim3(64 * NWG), NWG * lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2877,6 +2920,112 @@ static hipError_t launch_fused(const FusedArgs& a, unsigned grid, int nw, size_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_render_fused<LOOP, WAVES, PREC>), dim3(grid), dim3(64 * nw), lds, st, a);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bundle_size 1 / 4 (configs/dtu_pretrain.yaml:33 "bundle_size: 2  # 4 for 4*4"; network.py:31-34), second launch of the fused path: the
+// b^2 sub-ray colours of every bundle.  out[c b^2 + s] = sum over the bundle's samples k and the views v of wv[k][v] x the bilinear
+// colour c of source view v at the projection of sub-ray s's point o + d_s z_k - wv = normalised composite weight x softmax blend
+// weight, left by k_render_dense<.., BB = 1> - i.e. utils.py:109-119 applied to nerf.py:110's blend, the two sums exchanged.  One thread
+// per (bundle, sub-ray), the reference's own arithmetic per colour tap (world -> camera -> image as two products, IEEE divisions,
+// F.grid_sample border / align_corners=False: bundle_sampler.py:327-337, as the operator mirror k_encode_views).  The threads of a
+// bundle also move the bundle's other 29 values from the list kernel's packed rows (ld 41: [12 unused | feat (+) rgb 19 | feat_head 8 |
+// depth | opacity]) into the output rows (N_b, 3 b^2 + 27) + depth + opacity, or the packed (N_b, 3 b^2 + 29) form.
+struct ColArgs {
+    DevFrame f;
+    const float* wv; const float* tmp;
+    float* bf; float* depth; float* opac;   // depth / opac NULL: packed rows
+    int ldo;                                // floats per output row: 3 b^2 + 27, or + 2 packed
+    int row_begin, nrows;
+};
+template <int BB>
+__global__ void __launch_bounds__(256) k_bundle_colours(ColArgs a) {
+    const DevFrame& f = a.f;
+    constexpr int b = BB == 1 ? 1 : (BB == 4 ? 2 : 4);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nbs = (long long)f.B * a.nrows * f.W;     // bundles of the strip, all batch items
+    const long long bnd = t / BB;
+    const int s = (int)(t % BB);
+    if (bnd >= nbs) return;
+    const int x = (int)(bnd % f.W), rr = (int)(bnd / f.W), row = a.row_begin + rr % a.nrows, bi = rr / a.nrows;
+    const size_t gb = ((size_t)bi * f.H + row) * f.W + x;     // bundle index over the whole batch
+    const float* tc = tar_cam(f, bi);
+    float rng[4];
+    load_ranges(f, bi, row, x, rng);
+    float n0 = rng[0], f0 = rng[1];
+    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; }
+    const int cnt = sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive);
+    const float px = (float)(x * b + s % b) + 0.5f, py = (float)(row * b + s / b) + 0.5f;   // sub-ray order by * b + bx   bundle_sampler.py:100
+    float d[3];
+    ray_dir(tc + T_M, px, py, d);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < cnt; ++k) {
+        float z = sample_mid<false>(n0, f0, cnt, k);
+        if (f.inv_depth) z = 1.f / z;
+        const float p[3] = {tc[T_O] + d[0] * z, tc[T_O + 1] + d[1] * z, tc[T_O + 2] + d[2] * z};   // :255
+        const float* wp = a.wv + ((size_t)gb * f.S_max + k) * f.V;
+        for (int v = 0; v < f.V; ++v) {
+            const float* sc = src_cam(f, bi, v);
+            float cam[3], im[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cam[r] = sc[S_E + 4 * r] * p[0] + sc[S_E + 4 * r + 1] * p[1] + sc[S_E + 4 * r + 2] * p[2] + sc[S_E + 4 * r + 3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) im[r] = sc[S_K + 3 * r] * cam[0] + sc[S_K + 3 * r + 1] * cam[1] + sc[S_K + 3 * r + 2] * cam[2];
+            const float zc = fmaxf(im[2], 1e-6f);
+            const float gx = 2.f * (im[0] / zc) / (float)f.Wo - 1.f, gy = 2.f * (im[1] / zc) / (float)f.Ho - 1.f;
+            float rgb[3];
+            rgb_fetch(f.src_images + ((size_t)bi * f.V + v) * 3 * f.Ho * f.Wo, f.Ho, f.Wo, gx, gy, rgb);
+            const float w = wp[v];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = fmaf(w, rgb[c], acc[c]);
+        }
+    }
+    const int Q = 3 * BB + GDB_CFR + GDB_CV;
+    float* o = a.bf + gb * (size_t)a.ldo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c * BB + s] = acc[c];
+    const float* ti = a.tmp + gb * (size_t)(NOUT + 2) + 12;   // [feat (+) rgb 19 | feat_head 8 | depth | opacity] of the list kernel's row
+    for (int i = s; i < GDB_CFR + GDB_CV + 2; i += BB) {
+        const float val = ti[i];
+        if (i < GDB_CFR + GDB_CV) o[3 * BB + i] = val;
+        else if (a.ldo != Q) o[Q + (i - GDB_CFR - GDB_CV)] = val;
+        else if (i == GDB_CFR + GDB_CV) a.depth[gb] = val;
+        else a.opac[gb] = val;
+    }
+}
+
+static size_t solo_lds_bytes(int prec, int V);
+static bool dense_fits(const GdbFrame& fr);
+// The two launches of a bundle_size 1 / 4 render: the list kernel on the bundles' centre rays (dense schedule, two waves per workgroup,
+// the walk), then the colours.  f32x operand pairs are not built in this form: that precision runs the fp32 kernel (which is the more
+// exact of the two).
+template <int PREC, int WPS>
+static int render_center_launch(FusedArgs& a, const GdbConfig* cfg, const GdbFrame* fr, const WsLayout& L, const void* ws, bool plan_ready,
+                                float* bf, float* depth, float* opac, int ldo, hipStream_t st) {
+    if (!dense_fits(*fr)) return gdb_fail(GDB_E_SHAPE, "the dense schedule lists bundles and rows in 16 bits: W = %d, B x H = %lld (both must be < 65536)", fr->W, (long long)fr->B * fr->H);
+    if (!plan_ready) {
+        int rc = gdb_build_dense_plan(cfg, fr, const_cast<void*>(ws), st);
+        if (rc) return rc;
+    }
+    a.alias = 0;
+    a.bf = (float*)((char*)const_cast<void*>(ws) + L.colTmpOff); a.depth = nullptr; a.opac = nullptr; a.ldo = NOUT + 2;
+    a.wv = (float*)((char*)const_cast<void*>(ws) + L.colWvOff);
+    a.ntiles = a.nrows * a.f.planMW;
+    const size_t lds = (solo_lds_bytes(PREC, fr->V) + 15) / 16 * 16;
+    a.wave_floats = (int)(lds / sizeof(float));
+    if (2 * lds > (size_t)160 * 1024) return gdb_fail(GDB_E_SHAPE, "V=%d needs %zu B of LDS per wave (two waves per workgroup exceed 160 KiB)", fr->V, lds);
+    hipError_t e = launch_dense_n<PREC, WPS, 2, 1>(a, lds, st);
+    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_render_dense (centre rays): %s", hipGetErrorString(e));
+    ColArgs c;
+    c.f = a.f; c.wv = a.wv; c.tmp = a.bf; c.bf = bf; c.depth = depth; c.opac = opac; c.ldo = ldo; c.row_begin = a.row_begin; c.nrows = a.nrows;
+    const int BB = cfg->bundle_size * cfg->bundle_size;
+    const long long threads = (long long)fr->B * a.nrows * fr->W * BB;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (BB == 16) hipLaunchKernelGGL(k_bundle_colours<16>, dim3(grid), dim3(256), 0, st, c);
+    else hipLaunchKernelGGL(k_bundle_colours<1>, dim3(grid), dim3(256), 0, st, c);
+    e = hipGetLastError();
+    if (e != hipSuccess) return gdb_fail(GDB_E_HIP, "launch k_bundle_colours: %s", hipGetErrorString(e));
+    return GDB_OK;
 }
 
 // one-wave workgroups a CU holds by LDS (allocated in 1280-byte granules out of 160 KiB)
@@ -3017,10 +3166,10 @@ extern "C" int gdb_render_info(const GdbConfig* cfg, const GdbFrame* fr, int32_t
     if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X) return gdb_fail(GDB_E_BADARG, "precision %d unsupported", precision);
     if (row_begin < 0 || row_end > fr->H || row_begin > row_end) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) outside [0,%d]", row_begin, row_end, fr->H);
     const WsLayout L = ws_layout(*cfg, *fr);
-    out[0] = (cfg->bundle_size == 2 && fr->V >= 2) ? 1 : 0;
-    out[1] = out[0] ? resolve_schedule(*cfg, *fr, L, precision, row_end - row_begin, GDB_SCHED_AUTO) : 0;
+    out[0] = fr->V >= 2 ? 1 : 0;   // (bundle_size 1 / 4 since round 6: the dense list kernel on the centre rays + k_bundle_colours)
+    out[1] = !out[0] ? 0 : cfg->bundle_size != 2 ? GDB_SCHED_DENSE : resolve_schedule(*cfg, *fr, L, precision, row_end - row_begin, GDB_SCHED_AUTO);
     out[2] = (cfg->is_adaptive || gdb_fixed_counts_dense(*cfg, fr->V)) ? 1 : 0;   // gdb_prepare builds the plan when the frame carries d_depth_range (gdb_ops.hip prepare_common)
-    out[3] = out[0] ? ((out[1] == GDB_SCHED_FLAT || (out[1] == GDB_SCHED_DENSE && fr->B > 1 && !(row_begin == 0 && row_end == fr->H))) ? fr->B : 1) : 0;
+    out[3] = out[0] ? ((out[1] == GDB_SCHED_FLAT || (out[1] == GDB_SCHED_DENSE && fr->B > 1 && !(row_begin == 0 && row_end == fr->H))) ? fr->B : 1) + (cfg->bundle_size != 2 ? 1 : 0) : 0;
     return GDB_OK;
 }
 
@@ -3028,8 +3177,10 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
                         int32_t precision, int32_t schedule, float* bf, float* depth, float* opac, int ldo, void* stream_) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     rc = gdb_check_frame(cfg, fr, true); if (rc) return rc;
-    if (!ws || !pw || !bf || (ldo == NOUT && (!depth || !opac))) return gdb_fail(GDB_E_BADARG, "NULL pointer");
-    if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "fused kernel is built for bundle_size 2 (got %d); use the operator mirrors", cfg->bundle_size);
+    const bool packed = ldo != NOUT;
+    if (!ws || !pw || !bf || (!packed && (!depth || !opac))) return gdb_fail(GDB_E_BADARG, "NULL pointer");
+    const int b = cfg->bundle_size;
+    if (b != 2) ldo = 3 * b * b + GDB_CFR + GDB_CV + (packed ? 2 : 0);   // output rows of bundle_size 1 / 4: Q = 3 b^2 + 27
     if (precision != GDB_PREC_F16 && precision != GDB_PREC_F32 && precision != GDB_PREC_F32X)
         return gdb_fail(GDB_E_BADARG, "precision %d unsupported (0 = f16 MFMA operands with f32 accumulate, 1 = f32 MFMA, 2 = split-f16 operands)", precision);
     const bool plan_ready = (schedule & GDB_SCHED_PLAN_READY) != 0, pyr16_ready = (schedule & GDB_SCHED_PYR16_READY) != 0;
@@ -3053,7 +3204,7 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.row_begin = row_begin; a.nrows = row_end - row_begin;
     a.nseg = (fr->W + 31) / 32;
     a.nsegs = fr->B * a.nrows * a.nseg;
-    a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo;
+    a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo; a.wv = nullptr;
     a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1; a.flat_base = 0;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
@@ -3066,6 +3217,13 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
         if (L.pyrStride * 2 >= lim) return gdb_fail(GDB_E_SHAPE, "frame too large for the fused kernel: a per-view pyramid exceeds 4 GiB");
         rc = gdb_build_pyr16(cfg, fr, const_cast<void*>(ws), st);
         if (rc) return rc;
+    }
+    if (b != 2) {
+        // bundle_size 1 / 4: the dense list kernel on the bundles' centre rays, then the sub-ray colours (two launches; `schedule` beyond
+        // its flags is ignored: this form has the one schedule).  f32x runs the fp32 kernel.
+        // (f16: the three-waves-per-SIMD build - with the colour weights the centre-ray body spills four registers at four)
+        if (precision == GDB_PREC_F16) return render_center_launch<GDB_PREC_F16, 3>(a, cfg, fr, L, ws, plan_ready, bf, depth, opac, ldo, st);
+        return render_center_launch<GDB_PREC_F32, 2>(a, cfg, fr, L, ws, plan_ready, bf, depth, opac, ldo, st);
     }
     if (precision == GDB_PREC_F32) return render_launch<GDB_PREC_F32>(a, cfg, fr, L, ws, schedule, plan_ready, st);
     if (precision == GDB_PREC_F32X) return render_launch<GDB_PREC_F32X>(a, cfg, fr, L, ws, schedule, plan_ready, st);

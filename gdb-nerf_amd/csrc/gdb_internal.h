@@ -80,6 +80,9 @@ struct WsLayout {
     size_t pyr16Off;    // the half-precision copy of the feature pyramid the GDB_PREC_F16 render gathers from (PYR16_* below):
                         // 2 bytes per float of the fp32 pyramid, same (batch, view) stride and level offsets in elements
     size_t img16Off;    // the half-precision RGBA copy of the source images (IMG16_* below) behind it: at IMG16_REL(...) from pyr16Off
+    size_t boundsOff;   // gdb_prepare_rows: per (batch, view) the pyramid tiles / image rows a row strip's samples can reach (STRIP_BOUNDS ints)
+    size_t colTmpOff, colWvOff;  // bundle_size 1 / 4 (the two-launch fused path): the list kernel's packed rows (N_b x 41) and its per
+                                 // (sample slot, view) colour weights (N_b x S_max x V), read by k_bundle_colours; size 0 at bundle_size 2
 };
 
 // ---- half-precision pyramid (GDB_PREC_F16 only) ------------------------------------------------------------------------------
@@ -102,6 +105,9 @@ struct WsLayout {
 #define IMG16_REL(pyrStride, BV) ((((size_t)2 * (size_t)(pyrStride) * (size_t)(BV)) + PYR16_PAD + 255) / 256 * 256)
 
 #define SCAN_BLOCK 1024
+// gdb_prepare_rows: ints per (batch, view) of the strip's reach into a source view: [tile x lo, hi, tile y lo, hi (inclusive, 32 x 8-texel
+// pyramid tiles), image row lo, hi (inclusive, source pixels), whole (1: the bound could not be formed - build everything), unused]
+#define STRIP_BOUNDS 8
 // flat schedule: floats per (sample, lane half) record of a straddling bundle: 20 pre-weight values (16 blended + 4 feat_head),
 // alpha, the depth term, the boundary's header (map index, sample count) = 24 floats, padded to 32: ONE 128-byte line per record
 // (the region is 256-byte aligned), so that no line of the side buffer is shared between two records - i.e. between two lanes, two
@@ -164,6 +170,9 @@ static inline WsLayout ws_layout(const GdbConfig& c, const GdbFrame& f) {
     L.sideOff = off; off = align_up(off + sizeof(float) * FLAT_REC * 2 * (size_t)c.max_num_samples * ((size_t)L.flatMaxTiles + 1), 256);
     L.pyr16Off = off; off += IMG16_REL(L.pyrStride, (size_t)f.B * f.V);
     L.img16Off = off; off = align_up(off + (size_t)8 * f.B * f.V * f.Ho * f.Wo + 16, 256);
+    L.boundsOff = off; off = align_up(off + sizeof(int32_t) * STRIP_BOUNDS * (size_t)f.B * f.V, 256);
+    L.colTmpOff = off; if (c.bundle_size != 2) off = align_up(off + sizeof(float) * nb * 41, 256);
+    L.colWvOff = off;  if (c.bundle_size != 2) off = align_up(off + sizeof(float) * nb * (size_t)c.max_num_samples * f.V, 256);
     L.total = off;
     return L;
 }
@@ -367,6 +376,38 @@ __device__ __forceinline__ void load_bundle(const DevFrame& f, const float* __re
 template <int BB, bool FAST = false>
 __device__ __forceinline__ void load_bundle(const DevFrame& f, int bi, int h, int w, Bundle<BB>& q) {
     load_bundle<BB, FAST>(f, tar_cam(f, bi), bi, h, w, q);
+}
+
+// The bundle's CENTRE ray alone, for any bundle size b = f.b (the fused kernels at bundle_size 1 / 4, round 6): the mean of the b^2
+// sub-ray directions is the direction through the mean pixel (the rays are linear in the pixel: bundle_sampler.py:67-71, :99), the
+// mean of their normalised coordinates likewise (:104), and the mean of the sub-ray points o + d z is o + mean(d) z (:254-256) - the
+// same quantities the b^2-ray form sums up, to fp32 rounding.  q.d[0] = that mean direction; bundle_sample<1> then gives the sample's
+// centre point, its distance and ball radius.  The sub-ray colours are gathered elsewhere (k_bundle_colours).
+template <bool COUNT = true>
+__device__ __forceinline__ void load_bundle_center(const DevFrame& f, const float* __restrict__ tc, int bi, int h, int w, Bundle<1>& q,
+                                                   const float* pre = nullptr) {
+#pragma clang fp contract(off)
+    const float hb = 0.5f * (float)f.b;
+    const float x = (float)(w * f.b) + hb, y = (float)(h * f.b) + hb;   // mean of (w b + bx + 0.5), bx = 0 .. b - 1: exact in fp32
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q.d[0][i] = fmaf(tc[T_M + 3 * i], x, fmaf(tc[T_M + 3 * i + 1], y, tc[T_M + 3 * i + 2]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q.o[i] = tc[T_O + i];
+    q.u = gdiv<true>(2.f * x, (float)f.Wo) - 1.f;
+    q.v = gdiv<true>(2.f * y, (float)f.Ho) - 1.f;
+    const float* md = q.d[0];
+    const float nrm = sqrtf(fmaf(md[2], md[2], fmaf(md[1], md[1], md[0] * md[0])));
+    const float cosv = gdiv<true>(fmaf(md[2], tc[T_Z + 2], fmaf(md[1], tc[T_Z + 1], md[0] * tc[T_Z])), nrm);
+    q.unit = ball_unit_fast(tc[T_DISK], cosv);
+    float n0 = pre ? pre[0] : 0.f, f0 = pre ? pre[1] : 0.f, vn = pre ? pre[2] : 0.f, vf = pre ? pre[3] : 0.f;
+    if (!pre) {
+        float r[4];
+        load_ranges(f, bi, h, w, r);
+        n0 = r[0]; f0 = r[1]; vn = r[2]; vf = r[3];
+    }
+    if (f.inv_depth) { n0 = 1.f / n0; f0 = 1.f / f0; vn = 1.f / vn; vf = 1.f / vf; }
+    q.nearv = n0; q.farv = f0; q.vnear = vn; q.vfar = vf;
+    q.count = COUNT ? sample_count(n0, f0, tc[T_MINIV], f.S_max, f.adaptive) : 1;
 }
 
 // Mid depth of sample k of a bundle (in disparity when inv_depth): the one value the dense schedule's composite derives a second

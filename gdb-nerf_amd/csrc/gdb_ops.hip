@@ -228,6 +228,7 @@ struct PrepArgs {
     const float* depth_range; int* plan;
     unsigned* smap; int smapStride; int* nwin; int* nsamp;
     char* img16; int nimg;           // half-precision RGBA copy of the source images (gdb_internal.h IMG16_*): nimg workgroups of 512 pixels, or 0
+    const int* bounds;               // gdb_prepare_rows on a partial strip: per (batch, view) the tiles / image rows to build (k_strip_bounds), else NULL
     int* flat_cnt; int n_flat_cnt;   // flat schedule: the window boundaries' arrival counters, zeroed here once per frame (gdb_fused.hip: hand-off)
 };
 // The plan workgroups also clear the flat schedule's arrival counters (a render leaves them at zero again: the last arriver of a
@@ -375,12 +376,18 @@ __device__ __forceinline__ void store16_chunk(char* __restrict__ base, unsigned 
 
 // The half-precision RGBA copy of the source images (GDB_PREC_F16 renders take their colour taps from it): one thread per x pair of
 // pixels - three 8-byte loads (planar fp32), one 16-byte store (r, g, b, 0 | r, g, b, 0 as halves).  Wo is even (Wo = b W).
-__device__ __forceinline__ void img16_block(const float* __restrict__ src_images, char* __restrict__ img16, int nbv, int Ho, int Wo, int blk) {
+__device__ __forceinline__ void img16_block(const float* __restrict__ src_images, char* __restrict__ img16, int nbv, int Ho, int Wo, int blk,
+                                            const int* __restrict__ bounds = nullptr) {
     typedef _Float16 h8v __attribute__((ext_vector_type(8)));
     const size_t plane = (size_t)Ho * Wo, pairs = plane / 2;
     const size_t q = (size_t)blk * 256 + threadIdx.x;
     if (q >= pairs * (size_t)nbv) return;
     const size_t bv = q / pairs, p = (q - bv * pairs) * 2;   // first pixel of the pair inside the image
+    if (bounds) {   // a rank's row strip: only the image rows its samples' colour taps can reach (k_strip_bounds)
+        const int* bb = bounds + bv * STRIP_BOUNDS;
+        const int y = (int)(p / (size_t)Wo);
+        if (!bb[6] && (y < bb[4] || y > bb[5])) return;
+    }
     const float* im = src_images + bv * 3 * plane + p;
     const float2 r = *(const float2*)im, g = *(const float2*)(im + plane), b = *(const float2*)(im + 2 * plane);
     const h8v o = {(_Float16)r.x, (_Float16)g.x, (_Float16)b.x, (_Float16)0.f, (_Float16)r.y, (_Float16)g.y, (_Float16)b.y, (_Float16)0.f};
@@ -413,8 +420,13 @@ __global__ void __launch_bounds__(256) k_prepare(PrepArgs a) {
         return;
     }
     const int blk = (int)blockIdx.x - 1 - a.nplan;
-    if (blk >= a.ntiles) { img16_block(a.src_images, a.img16, a.B * a.V, a.Ho, a.Wo, blk - a.ntiles); return; }
+    if (blk >= a.ntiles) { img16_block(a.src_images, a.img16, a.B * a.V, a.Ho, a.Wo, blk - a.ntiles, a.bounds); return; }
     const int tx = blk % a.tilesX, ty = (blk / a.tilesX) % a.tilesY, bv = blk / (a.tilesX * a.tilesY);
+    if (a.bounds) {   // a rank's row strip (gdb_prepare_rows): this tile only if the strip's samples can reach it (k_strip_bounds, an earlier launch)
+        typedef const int __attribute__((address_space(4))) kint;
+        kint* bb = (kint*)(a.bounds + (size_t)bv * STRIP_BOUNDS);
+        if (!bb[6] && (tx < bb[0] || tx > bb[1] || ty < bb[2] || ty > bb[3])) return;
+    }
     const int x0 = tx * PT_W, y0 = ty * PT_H;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
@@ -533,10 +545,105 @@ int gdb_build_pyr16(const GdbConfig* cfg, const GdbFrame* f, void* ws, hipStream
     LAUNCH_CHECK("k_pyr16");
     hipMemsetAsync((char*)ws + L.pyr16Off + (size_t)2 * L.pyrStride * f->B * f->V, 0, PYR16_PAD, st);
     if (!f->d_src_images) return gdb_fail(GDB_E_BADARG, "a GDB_PREC_F16 render needs frame->d_src_images");
+    if (cfg->bundle_size != 2) return GDB_OK;   // (the x-pair image copy is the bundle_size 2 kernels': k_bundle_colours reads the fp32 images)
     const size_t npair = (size_t)f->B * f->V * f->Ho * f->Wo / 2;
     hipLaunchKernelGGL(k_img16, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, st, f->d_src_images, (char*)ws + L.img16Off, f->B * f->V, f->Ho, f->Wo);
     LAUNCH_CHECK("k_img16");
     return GDB_OK;
+}
+
+// ---- gdb_prepare_rows: what of the source views a row strip's samples can reach (round 6; SURVEY.md 8(e), VERDICT r05 task 4) --------------
+// A rank that renders the bundle-map rows [r0, r1) needs, of every source view, only the pyramid texels (all levels) and image pixels its
+// samples project onto.  Every point the strip samples - sub-ray points o + d(x, y) z and their bundle means - lies in the truncated
+// pyramid { o + M [x, y, 1]^T z : (x, y) in [0, Wo] x [r0 b, r1 b], z in [z_min, z_max] } (bundle_sampler.py:67-71, :254-256), z_min / z_max =
+// the extremes of the strip's depth prior (a sample's depth lies between its bundle's near and far, in depth and in disparity sampling:
+// :122-191).  That body is convex, so while its 8 vertices lie in front of a source camera (K (E p + t) has z >= a positive floor) its
+// perspective image is the convex hull of theirs and the bounding box of the 8 projections bounds every tap coordinate.  Margins: a
+// bilinear tap pair at mip level l reaches 1.5 * 2^l level-0 texels from the level-0 coordinate (12 at level 3), + 2 for the rounding of
+// this fp32 estimate against the render's own arithmetic; colour taps 1 pixel + 1.  Anything the construction cannot vouch for - a vertex
+// behind or near a source camera's plane, a non-finite or non-positive depth in the strip - sets `whole`: that view is built in full.
+// One workgroup per batch item: the strip's depth extremes by a block reduction, then one thread per view.  All fp32, closed-form
+// inverses; the camera block proper (fp64) is k_prepare's.
+struct BoundsArgs {
+    int B, V, H, W, Ho, Wo, b, r0, r1, tilesX, tilesY;
+    const float* depth_range; const float* tar_exts; const float* tar_ints; const float* src_exts; const float* src_ints;
+    int* bounds;
+};
+#define SB_THREADS 1024
+#define SB_UNROLL 8
+__global__ void __launch_bounds__(SB_THREADS) k_strip_bounds(BoundsArgs a) {
+    __shared__ float s_lo[SB_THREADS / 64], s_hi[SB_THREADS / 64];
+    __shared__ int s_bad[SB_THREADS / 64];
+    const int bi = (int)blockIdx.x, t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    const size_t hw = (size_t)a.H * a.W;
+    const float* nearp = a.depth_range + ((size_t)bi * 2) * hw + (size_t)a.r0 * a.W;
+    const float* farp = nearp + hw;
+    const int n = (a.r1 - a.r0) * a.W;
+    float lo = INFINITY, hi = -INFINITY; int bad = 0;
+    // (this workgroup is a latency chain ahead of k_prepare: 2 SB_UNROLL loads per thread in flight per round trip - c5's strip of 75 rows
+    // x 800 bundles is 8 round trips this way, 470 with one load at a time in 256 threads)
+    for (int i0 = t; i0 < n; i0 += SB_THREADS * SB_UNROLL) {
+        float x[SB_UNROLL], y[SB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; ++u) {
+            const int i = i0 + u * SB_THREADS;
+            x[u] = i < n ? nearp[i] : 1.f; y[u] = i < n ? farp[i] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB_UNROLL; ++u) {
+            if (i0 + u * SB_THREADS < n) {
+                if (!(x[u] > 0.f) || !(y[u] > 0.f) || !(fabsf(x[u]) < INFINITY) || !(fabsf(y[u]) < INFINITY)) bad = 1;   // (NaN fails every comparison)
+                lo = fminf(lo, fminf(x[u], y[u])); hi = fmaxf(hi, fmaxf(x[u], y[u]));
+            }
+        }
+    }
+    for (int d = 32; d; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d)); hi = fmaxf(hi, __shfl_xor(hi, d)); bad |= __shfl_xor(bad, d); }
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; s_bad[wv] = bad; }
+    __syncthreads();
+    if (t >= a.V) return;
+    float zmin = INFINITY, zmax = -INFINITY; int anybad = 0;
+    for (int i = 0; i < SB_THREADS / 64; ++i) { zmin = fminf(zmin, s_lo[i]); zmax = fmaxf(zmax, s_hi[i]); anybad |= s_bad[i]; }
+    int whole = anybad || !(zmin > 0.f) || !(zmax >= zmin) || n <= 0;
+    int* out = a.bounds + ((size_t)bi * a.V + t) * STRIP_BOUNDS;
+    // target camera: c2w = E^-1, ray matrix M = R_c2w K^-1 (fp32 closed forms; k_prepare's camera block does the same in fp64)
+    const float* E = a.tar_exts + bi * 16; const float* K = a.tar_ints + bi * 9;
+    double Ed[16], Ei[16], Kd[9], Ki[9];
+    for (int i = 0; i < 16; ++i) Ed[i] = E[i];
+    for (int i = 0; i < 9; ++i) Kd[i] = K[i];
+    invert4_f64(Ed, Ei); invert3_f64(Kd, Ki);
+    float M[9], o[3];
+    for (int i = 0; i < 3; ++i) {
+        o[i] = (float)Ei[i * 4 + 3];
+        for (int j = 0; j < 3; ++j) M[3 * i + j] = (float)(Ei[i * 4] * Ki[j] + Ei[i * 4 + 1] * Ki[3 + j] + Ei[i * 4 + 2] * Ki[6 + j]);
+    }
+    const float* Es = a.src_exts + ((size_t)bi * a.V + t) * 16; const float* Ks = a.src_ints + ((size_t)bi * a.V + t) * 9;
+    float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    const float floor_z = 1e-3f * zmin;   // a vertex this close to the camera plane (or behind it): no bound
+    for (int c = 0; c < 8 && !whole; ++c) {
+        const float px = (c & 1) ? (float)a.Wo : 0.f, py = (c & 2) ? (float)(a.r1 * a.b) : (float)(a.r0 * a.b), z = (c & 4) ? zmax : zmin;
+        float p[3], cam[3], im[3];
+        for (int i = 0; i < 3; ++i) p[i] = o[i] + (M[3 * i] * px + M[3 * i + 1] * py + M[3 * i + 2]) * z;
+        for (int r = 0; r < 3; ++r) cam[r] = Es[4 * r] * p[0] + Es[4 * r + 1] * p[1] + Es[4 * r + 2] * p[2] + Es[4 * r + 3];
+        for (int r = 0; r < 3; ++r) im[r] = Ks[3 * r] * cam[0] + Ks[3 * r + 1] * cam[1] + Ks[3 * r + 2] * cam[2];
+        if (!(im[2] > floor_z) || !(fabsf(im[0]) < INFINITY) || !(fabsf(im[1]) < INFINITY)) { whole = 1; break; }
+        const float u = im[0] / im[2], v = im[1] / im[2];
+        xlo = fminf(xlo, u); xhi = fmaxf(xhi, u); ylo = fminf(ylo, v); yhi = fmaxf(yhi, v);
+    }
+    if (!whole && !(fabsf(xlo) < 1e9f && fabsf(xhi) < 1e9f && fabsf(ylo) < 1e9f && fabsf(yhi) < 1e9f)) whole = 1;
+    if (whole) { out[0] = 0; out[1] = a.tilesX - 1; out[2] = 0; out[3] = a.tilesY - 1; out[4] = 0; out[5] = a.Ho - 1; out[6] = 1; out[7] = 0; return; }
+    // source pixels -> level-0 texel coordinates of the feature pyramid: pixel / b - 0.5 (S_KS: rows 0, 1 of K divided by b; :311-312, :351-353)
+    // The margins go AROUND THE CLAMPED coordinate (clamp-to-edge / border addressing clamps the coordinate first and then reads texel
+    // floor(c) and its neighbour floor(c) + 1 - with weight 0 at the edge, but it is read - at every level): a body that projects wholly
+    // outside a map still reads the map's first / last texels and their neighbours.
+    const float ib = 1.f / (float)a.b, mt = 14.f;
+    auto clampf = [](float v, float hi) { return fminf(fmaxf(v, 0.f), hi); };
+    const float tx0 = fmaxf(clampf(xlo * ib - 0.5f, (float)(a.W - 1)) - mt, 0.f), tx1 = fminf(clampf(xhi * ib - 0.5f, (float)(a.W - 1)) + mt, (float)(a.W - 1));
+    const float ty0 = fmaxf(clampf(ylo * ib - 0.5f, (float)(a.H - 1)) - mt, 0.f), ty1 = fminf(clampf(yhi * ib - 0.5f, (float)(a.H - 1)) + mt, (float)(a.H - 1));
+    out[0] = (int)floorf(tx0) / PT_W; out[1] = min((int)floorf(tx1) / PT_W, a.tilesX - 1);
+    out[2] = (int)floorf(ty0) / PT_H; out[3] = min((int)floorf(ty1) / PT_H, a.tilesY - 1);
+    out[4] = (int)fmaxf(floorf(clampf(ylo - 0.5f, (float)(a.Ho - 1))) - 2.f, 0.f);
+    out[5] = (int)fminf(ceilf(clampf(yhi - 0.5f, (float)(a.Ho - 1))) + 2.f, (float)(a.Ho - 1));
+    out[6] = 0; out[7] = 0;
 }
 
 static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* fpn_feat, int flags, void* ws, size_t ws_bytes, void* stream_, int row_begin = 0, int row_end = -1);
@@ -582,6 +689,7 @@ extern "C" int gdb_prepare_rows(const GdbConfig* cfg, const GdbFrame* f, const f
     if ((flags & GDB_PREP_PYR16_ONLY) && !(flags & GDB_PREP_PYR16)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: GDB_PREP_PYR16_ONLY needs GDB_PREP_PYR16");
     if (d_fpn_feat && (!f || !f->d_src_images)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows with d_fpn_feat resamples frame->d_src_images: it is NULL");
     if (row_end < 0) return gdb_fail(GDB_E_SHAPE, "row strip [%d,%d) is negative", row_begin, row_end);
+    if ((flags & GDB_PREP_STRIP_REACH) && (flags & GDB_PREP_STRIP_WHOLE)) return gdb_fail(GDB_E_BADARG, "gdb_prepare_rows: GDB_PREP_STRIP_REACH and GDB_PREP_STRIP_WHOLE exclude each other");
     return prepare_common(cfg, f, d_fpn_feat, flags, ws, ws_bytes, stream_, row_begin, row_end);
 }
 
@@ -645,6 +753,29 @@ static int prepare_common(const GdbConfig* cfg, const GdbFrame* f, const float* 
     // configs - the operator mirrors' - never read it)
     a.img16 = (a.pyr16 && f->d_src_images && a.ntiles && cfg->bundle_size == 2 && (((size_t)f->Ho * f->Wo) & 1) == 0) ? (char*)ws + L.img16Off : nullptr;
     a.nimg = a.img16 ? (int)(((size_t)f->B * f->V * f->Ho * f->Wo / 2 + 255) / 256) : 0;
+    // A rank's row strip (gdb_prepare_rows on fewer rows than the frame has): only the pyramid tiles / image rows the strip's samples can
+    // reach are built - k_strip_bounds, a launch of its own ahead of this one (the tiles read its result), decides per (batch, view).
+    // Renders of rows OUTSIDE [row_begin, row_end) are then invalid on this workspace until a prepare of the whole frame.
+    a.bounds = nullptr;
+    bool reach = a.ntiles && a.plan_nr > 0 && a.plan_nr < f->H && f->d_depth_range && f->d_src_exts && !(flags & GDB_PREP_STRIP_WHOLE);
+    if (reach && !(flags & GDB_PREP_STRIP_REACH)) {
+        // by size: the bound is a launch of its own ahead of the tiles (a one-workgroup latency chain + a kernel boundary, ~8 us of stream
+        // time) - worth it once the whole-frame tile work moves >= 128 MB (per texel 76 B read, 106 B of fp32 pyramid, 53 B of
+        // half-precision pyramid; per source pixel 20 B for the half-precision image copy)
+        const size_t texels = (size_t)f->B * f->V * f->H * f->W, px = (size_t)f->B * f->V * f->Ho * f->Wo;
+        const size_t est = texels * (76 + (a.pyr ? 106 : 0) + (a.pyr16 ? 53 : 0)) + (a.img16 ? px * 20 : 0);
+        reach = est >= ((size_t)128 << 20);
+    }
+    if (reach) {
+        BoundsArgs b{};
+        b.B = f->B; b.V = f->V; b.H = f->H; b.W = f->W; b.Ho = f->Ho; b.Wo = f->Wo; b.b = cfg->bundle_size; b.r0 = row_begin; b.r1 = row_end;
+        b.tilesX = a.tilesX; b.tilesY = a.tilesY;
+        b.depth_range = f->d_depth_range; b.tar_exts = f->d_tar_exts; b.tar_ints = f->d_tar_ints; b.src_exts = f->d_src_exts; b.src_ints = f->d_src_ints;
+        b.bounds = (int*)((char*)ws + L.boundsOff);
+        hipLaunchKernelGGL(k_strip_bounds, dim3(f->B), dim3(SB_THREADS), 0, st, b);
+        LAUNCH_CHECK("k_strip_bounds");
+        a.bounds = b.bounds;
+    }
     hipLaunchKernelGGL(k_prepare, dim3(a.ntiles + 1 + a.nplan + a.nimg), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_prepare");
     return GDB_OK;

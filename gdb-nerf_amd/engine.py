@@ -97,6 +97,9 @@ class HotPathEngine:
         self._fused_ok = None
         self._fpn_ptr = None
         self.f16_only_prepare = True   # a PREC_F16 engine's prepare() writes the half-precision pyramid alone (see prepare)
+        # prepare(rows=strip): None = the library decides by frame size whether the strip builds only its reach of the pyramid(s)
+        # (GDB_PREP_STRIP_REACH / _WHOLE: True / False force it)
+        self.strip_reach: Optional[bool] = None
         self.schedule = _lib.SCHED_AUTO
         self.precision = _lib.PREC_F32  # the reference computes in fp32 (nerf.py:84-115); PREC_F16 is the opt-in fast path
         self.reuse_outputs = False
@@ -241,14 +244,20 @@ class HotPathEngine:
         if sources_unchanged and src_key is not None and src_key == getattr(self, "_src_key", None):
             flags |= _lib.PREP_SOURCES_READY
         self._src_key = None   # armed again once the launch below has been accepted
+        # a row strip smaller than the frame builds only the part of the pyramid(s) its samples can reach (gdb_prepare_rows, round 6):
+        # renders of other rows, the operator mirrors and feature_pyramid() then prepare again in full first (_need_whole)
+        partial = rows is not None and (int(rows[0]) > 0 or int(rows[1]) < H) and "src_images" in frame and not (flags & _lib.PREP_SOURCES_READY)
         self._plan_rows = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
         if rows is None:
             _lib.check(self.lib.gdb_prepare_ex(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags,
                                                self._ws.data_ptr(), self._ws.numel(), self._stream()))
         else:
-            _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
+            sflag = 0 if self.strip_reach is None else (_lib.PREP_STRIP_REACH if self.strip_reach else _lib.PREP_STRIP_WHOLE)
+            partial = partial and self.strip_reach is not False   # (by size: the engine cannot know - it assumes the strip's reach alone)
+            _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(f), self._fpn_ptr, flags | sflag, self._plan_rows[0], self._plan_rows[1],
                                                  self._ws.data_ptr(), self._ws.numel(), self._stream()))
-        self._src_key = src_key
+        self._src_key = None if partial else src_key   # (a partial pyramid is no basis for a later sources_unchanged prepare)
+        self._pyr_partial = partial
         self._pyr16_ready = bool(flags & _lib.PREP_PYR16)
         self._pyr32_ready = not (flags & _lib.PREP_PYR16_ONLY)
         if self.cfg.is_adaptive:
@@ -277,8 +286,19 @@ class HotPathEngine:
             self._fused_ok = bool(self.render_info()["fused"])
         return self._fused_ok
 
+    def _need_whole(self, row_begin: int = 0, row_end: Optional[int] = None) -> None:
+        """The pyramid(s) of the WHOLE frame: after a prepare(rows=strip) that built only the strip's reach (`_pyr_partial`), anything that
+        looks beyond the strip - a render of other rows, the operator mirrors, feature_pyramid() - prepares the kept frame again in full."""
+        if not getattr(self, "_pyr_partial", False) or self._frame is None:
+            return
+        p0, p1 = self._plan_rows
+        if row_begin >= p0 and (self._frame.H if row_end is None else row_end) <= p1 and row_end is not None:
+            return
+        self.prepare(self._keep)
+
     def _need_pyr32(self) -> None:
         """The fp32 feature pyramid of the frame last prepared, built now if that prepare wrote the half-precision copy alone."""
+        self._need_whole()
         if getattr(self, "_pyr32_ready", True) or self._frame is None:
             return
         flags = _lib.PREP_PYR16 if self._pyr16_ready else 0
@@ -286,6 +306,19 @@ class HotPathEngine:
                                              self._ws.data_ptr(), self._ws.numel(), self._stream()))
         self._pyr32_ready = True
         self._src_key = None   # (the workspace now holds other products than the key describes: the next prepare() runs in full)
+
+    def _need_pyr32_strip(self, row_begin: int, row_end: int) -> None:
+        """_need_pyr32 for a render of rows that lie inside a partial prepare's strip: the fp32 pyramid of that strip's reach suffices."""
+        if getattr(self, "_pyr32_ready", True) or self._frame is None:
+            return
+        if getattr(self, "_pyr_partial", False):   # (rows inside the strip: _need_whole has returned without preparing)
+            flags = _lib.PREP_PYR16 if self._pyr16_ready else 0
+            flags |= 0 if self.strip_reach is None else _lib.PREP_STRIP_REACH
+            _lib.check(self.lib.gdb_prepare_rows(C.byref(self.cfg), C.byref(self._frame), self._fpn_ptr, flags, self._plan_rows[0], self._plan_rows[1],
+                                                 self._ws.data_ptr(), self._ws.numel(), self._stream()))
+            self._pyr32_ready = True
+            return
+        self._need_pyr32()
 
     @staticmethod
     def _prior_key(dr: Optional[torch.Tensor]):
@@ -425,6 +458,7 @@ class HotPathEngine:
         """The HALF-precision copy of the pyramid (what a PREC_F16 render gathers from), per level (B, V, H_l, W_l, C_f+3) float16
         (copies).  Only meaningful after a prepare() of a PREC_F16 engine or after an f16 render (which builds it on demand)."""
         f = self._need_frame()
+        self._need_whole()
         out = (C.c_size_t * 7)()
         _lib.check(self.lib.gdb_pyramid16_layout(C.byref(self.cfg), C.byref(f), out))
         off, stride, levels = out[0], out[1], out[2]
@@ -617,8 +651,9 @@ class HotPathEngine:
         f = self._need_frame()
         row_end = f.H if row_end is None else row_end
         precision = self.precision if precision is None else precision
+        self._need_whole(row_begin, row_end)
         if precision != _lib.PREC_F16:
-            self._need_pyr32()
+            self._need_pyr32_strip(row_begin, row_end)
         nb = self.n_bundles
         if out is None:
             if row_begin == 0 and row_end == f.H:  # every row is written: a reused buffer needs no zero-fill
@@ -644,8 +679,9 @@ class HotPathEngine:
         f = self._need_frame()
         row_end = f.H if row_end is None else row_end
         precision = self.precision if precision is None else precision
+        self._need_whole(row_begin, row_end)
         if precision != _lib.PREC_F16:
-            self._need_pyr32()
+            self._need_pyr32_strip(row_begin, row_end)
         nb = self.n_bundles
         if out is None:
             full = row_begin == 0 and row_end == f.H

@@ -171,14 +171,27 @@ int gdb_prepare_fpn(const GdbConfig* cfg, const GdbFrame* frame, const float* d_
 #define GDB_PREP_PYR16 1
 #define GDB_PREP_PYR16_ONLY 2
 #define GDB_PREP_SOURCES_READY 4
-#define GDB_PREP_ALL (GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY | GDB_PREP_SOURCES_READY)
+/* gdb_prepare_rows only: whether a strip smaller than the frame builds just its reach of the source-only products (see there).  Neither
+ * flag: by size - the bound costs a launch of its own ahead of the tiles (~8 us of stream time), which pays once the whole-frame tile
+ * work moves >= 128 MB (1200x1600 with 5 views at f16: 95 -> 46 us per rank at 8 ranks; at 512x640 it would cost 3 us more than it saves:
+ * profiles/r06/time_prepare_rows_world8.json). */
+#define GDB_PREP_STRIP_REACH 8   /* always build the strip's reach only */
+#define GDB_PREP_STRIP_WHOLE 16  /* always build the whole pyramid (a later render of other rows stays valid) */
+#define GDB_PREP_ALL (GDB_PREP_PYR16 | GDB_PREP_PYR16_ONLY | GDB_PREP_SOURCES_READY | GDB_PREP_STRIP_REACH | GDB_PREP_STRIP_WHOLE)
 int gdb_prepare_ex(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, void* d_workspace,
                    size_t workspace_bytes, void* stream);
 
-/* gdb_prepare_ex for a rank that renders ONE row strip of the frame (multi-GPU row sharding; ABI v6): camera block and
- * feature pyramid as ever (a strip's samples project anywhere into the source views), the list schedules' plan for the bundle-map
- * rows [row_begin, row_end) of every batch item only - the rows outside the strip are another rank's.  GDB_SCHED_PLAN_READY then
- * holds for render calls whose strip lies inside [row_begin, row_end). */
+/* gdb_prepare_ex for a rank that renders ONE row strip of the frame (multi-GPU row sharding; ABI v6): the camera block as
+ * ever, the list schedules' plan for the bundle-map rows [row_begin, row_end) of every batch item only - the rows outside the strip are
+ * another rank's - and, when the strip is smaller than the frame (round 6), only the PART of the source-only products the strip's samples
+ * can reach: per (batch, view) a launch of its own ahead of the tiles (k_strip_bounds) takes the extremes of the strip's depth prior
+ * (a sample's depth lies between its bundle's near and far, bundle_sampler.py:122-191), projects the 8 vertices of the convex body
+ * { o + d(x, y) z : (x, y) in the strip's pixel rectangle, z in [z_min, z_max] } (bundle_sampler.py:67-71, :254-256) into the view and
+ * builds only the 32 x 8-texel pyramid tiles (all mip levels) and the image rows (half-precision copy) inside that box + the mip /
+ * bilinear margins; a view it cannot bound (a vertex behind or near the camera plane, a non-finite or non-positive depth) is built
+ * whole.  It reads d_depth_range, so the frame must carry it.  GDB_SCHED_PLAN_READY holds for render calls whose strip lies inside
+ * [row_begin, row_end); RENDERS OF ROWS OUTSIDE IT ARE INVALID on this workspace until a prepare of the whole frame (and so are
+ * gdb_encode / GDB_PREP_SOURCES_READY, which read the whole pyramid). */
 int gdb_prepare_rows(const GdbConfig* cfg, const GdbFrame* frame, const float* d_fpn_feat, int32_t flags, int32_t row_begin,
                      int32_t row_end, void* d_workspace, size_t workspace_bytes, void* stream);
 
@@ -284,7 +297,13 @@ int gdb_accumulate(const GdbConfig* cfg, const float* d_weights, const float* d_
  *   the result is undefined but memory-safe: the kernel clamps everything it reads from the plan to the frame.)
  * Both are per-call arguments: the library keeps no process-global state (two engines with different settings may
  * interleave calls on different streams or threads).
- * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W). */
+ * Outputs d_bundle_feat (B*H*W, 3b²+C_f+3+C_v), d_depth, d_opacity (B*H*W).
+ * bundle_size 1 and 4 (network.py:31-34; configs/dtu_pretrain.yaml:33 "4 for 4*4"; since round 6): TWO launches - the dense list kernel
+ * on the bundles' CENTRE rays (everything of a sample but its 3b² sub-ray colours, which the MLP never sees: nerf.py:98), which also
+ * leaves per (sample, view) the weight those colours get in the bundle's output (normalised composite weight x softmax blend weight,
+ * utils.py:35-41, nerf.py:108-110), then k_bundle_colours: one thread per (bundle, sub-ray) gathers the colours with the reference's own
+ * per-tap arithmetic (bundle_sampler.py:327-337) and assembles the rows.  `schedule` beyond its flags is ignored there (the one
+ * schedule is DENSE), GDB_PREC_F32X runs the fp32 kernel; rows strips, batches and both output layouts as for bundle_size 2. */
 #define GDB_PREC_F16 0
 #define GDB_PREC_F32 1
 #define GDB_PREC_F32X 2
@@ -303,12 +322,13 @@ int gdb_render_bundles_fused(const GdbConfig* cfg, const GdbFrame* frame, const 
 
 /* What the two fused entries would do for this (config, frame shape, precision, row strip), without launching anything (ABI v6): the
  * library's own answer, so that no caller restates its rules.  shape needs B, V, Ho, Wo, H, W, D (no pointers).
- *   out[0]  1 when gdb_render_bundles_fused / _packed accept the config and frame (bundle_size 2, >= 2 source views); 0: only the operator
- *           mirrors above run it (gdb_sample -> gdb_encode -> gdb_mlp -> gdb_composite; bundle_size 1 and 4).
+ *   out[0]  1 when gdb_render_bundles_fused / _packed accept the config and frame (>= 2 source views; bundle_size 1, 2 or 4 since round
+ *           6); 0: only the operator mirrors above run it (gdb_sample -> gdb_encode -> gdb_mlp -> gdb_composite).
  *   out[1]  the schedule GDB_SCHED_AUTO resolves to for this call (GDB_SCHED_SLOT_WAVES .. GDB_SCHED_FLAT; 0 when out[0] is 0).
  *   out[2]  1 when gdb_prepare builds the list schedules' plan for this config if the frame it is given carries d_depth_range - i.e. when a
  *           render of that frame may be passed GDB_SCHED_PLAN_READY (adaptive counts: while the contents of d_depth_range are unchanged).
- *   out[3]  kernel launches the render enqueues (1; one per batch item for the flat schedule and for a dense row strip of a batch). */
+ *   out[3]  kernel launches the render enqueues (1; one per batch item for the flat schedule and for a dense row strip of a batch; one
+ *           more - k_bundle_colours - at bundle_size 1 / 4). */
 int gdb_render_info(const GdbConfig* cfg, const GdbFrame* shape, int32_t precision, int32_t row_begin, int32_t row_end, int32_t out[4]);
 
 /* The same with ONE output buffer d_out (B*H*W, Q+2), row = [bundle_feat (Q) | depth | opacity]: what

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/r06e; mkdir -p $OUT; cd $ROOT
+echo "== pytest partial pyramid"; timeout -k 10 600 python3 -m pytest tests/test_hip_parity.py tests/test_parallel.py -m gpu -q -s -k "prepare_rows or row_strips or strip_gather or two_ranks" > $OUT/pytest_new.txt 2>&1; echo "rc=$?"; tail -3 $OUT/pytest_new.txt
+grep -h "partial pyramid" $OUT/pytest_new.txt
+echo "== strip prepare timing"; timeout -k 10 400 python3 tools/time_prepare_rows.py 8 200 > $OUT/time_prepare_rows_world8.json 2> $OUT/time_prepare_rows.err; tail -2 $OUT/time_prepare_rows.err
+python3 - <<PY
+import json
+d = json.load(open("$OUT/time_prepare_rows_world8.json"))
+for k, v in d.items():
+    if isinstance(v, dict): print(k, "whole", round(v["whole_frame_prepare_us"], 1), "strip mean", round(v["strip_prepare_us_mean"], 1), "max", round(v["strip_prepare_us_max"], 1), "ratio", round(v["strip_over_whole"], 2), "render whole", round(v["whole_frame_render_us"], 1), "strip renders", [round(s["render_us"], 1) for s in v["strips"]])
+PY
+echo "== full gpu suite"; timeout -k 10 800 python3 -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.txt 2>&1; echo "rc=$?"; tail -4 $OUT/pytest_gpu.txt
