@@ -440,6 +440,7 @@ struct FusedArgs {
     float* bf; float* depth; float* opac;  // depth / opac unused (NULL) in the packed layout
     float* wv;        // bundle_size 1 / 4 only: per (bundle, sample slot, view) the colour weight k_bundle_colours applies (else NULL)
     unsigned* dbg;    // diagnostic build only
+    int xp_stagger, xp_per_rank;   // diagnostic build only (GDB_XP_STAGGER): start-of-launch stagger of the list kernels' waves by their rank on the CU
 };
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte store to a 4-byte aligned address (gfx950: dword alignment suffices)
 // nb rows of the record -> bf[b0 ...] (and depth / opac in the three-tensor form); the whole wave calls it
@@ -2425,6 +2426,20 @@ __device__ __forceinline__ void render_list_body(const FusedArgs& a_) {
         }
     }
     if (ntile <= 0) return;
+#ifdef GDB_DIAG
+    // Experiment (GDB_XP_STAGGER = n, diagnostic build; profiles/r06/xp_start_stagger.txt): the waves of a CU start their first gather
+    // together - a burst on the memory system with the matrix pipe idle - and the oldest workgroups of a CU then finish 30 us before
+    // the youngest.  n > 0: the workgroup of dispatch rank r on its CU (0 = oldest of R) sleeps (R - 1 - r) x n x 4,096
+    // cycles before its first tile (the old ones, which have the slack, yield the start); n < 0: rank r sleeps r x |n| x 4,096.
+    {
+        const FusedArgs& a = *(const FusedArgs*)ap;
+        if (a.xp_stagger && a.xp_per_rank > 0) {
+            const int slot = (int)(blockIdx.x >> 3), R = max(((int)(gridDim.x >> 3) + a.xp_per_rank - 1) / a.xp_per_rank, 1), r = min(slot / a.xp_per_rank, R - 1);
+            const int n = a.xp_stagger > 0 ? (R - 1 - r) * a.xp_stagger : r * -a.xp_stagger;
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+#endif
     int it = 0;
     // flat: the arrival ticket of the tile just rendered and which of its two boundaries it arrived at (bit 0: the one before it, bit 1:
     // the one behind it; 0: nothing pending).  The ticket is READ at the top of the next tile (or behind the loop): by then the output
@@ -3072,7 +3087,9 @@ static int resolve_schedule(const GdbConfig& cfg, const GdbFrame& fr, const WsLa
     const int S = cfg.max_num_samples, V = fr.V;
     const bool one_wave_fits = solo_lds_bytes(prec, V) <= (size_t)160 * 1024;
     const long long slots = 12LL * device_cus();   // resident wave slots at three waves per SIMD
-    const bool flat_wins = prec == GDB_PREC_F32 && S <= 4 && ((long long)nrows * fr.W * S + 31) / 32 + 1 <= 3 * slots;   // worst case <= 3 tiles per wave slot
+    // (B <= 2: the flat schedule launches once per batch item, the dense one once for all of them - c2 fp32, us per frame at B = 1 / 2 / 4: flat
+    // 93.7 / 94.5 / 95.6, dense 97.6 / 94.5 / 89.1: profiles/r06/xp_frames_per_launch.txt)
+    const bool flat_wins = prec == GDB_PREC_F32 && S <= 4 && fr.B <= 2 && ((long long)nrows * fr.W * S + 31) / 32 + 1 <= 3 * slots;   // worst case <= 3 tiles per wave slot
     if (one_wave_fits) {
         if (sched == GDB_SCHED_FLAT || (sched == GDB_SCHED_AUTO && cfg.is_adaptive && flat_fits(cfg, fr, L) && flat_wins)) return GDB_SCHED_FLAT;
         if (sched == GDB_SCHED_DENSE || (sched == GDB_SCHED_AUTO && dense_fits(fr) &&
@@ -3206,9 +3223,12 @@ static int render_entry(const GdbConfig* cfg, const GdbFrame* fr, const void* ws
     a.nsegs = fr->B * a.nrows * a.nseg;
     a.bf = bf; a.depth = depth; a.opac = opac; a.ldo = ldo; a.wv = nullptr;
     a.dbg = nullptr; a.skip = 0; a.wave_floats = 0; a.row_lo = a.row_hi = 0; a.tile_stride = 1; a.flat_base = 0;
+    a.xp_stagger = 0; a.xp_per_rank = 0;
 #ifdef GDB_DIAG  // diagnostic build: timing-only ablation bits from the environment, stamp buffer
     static const int env_skip = getenv("GDB_FUSED_SKIP") ? atoi(getenv("GDB_FUSED_SKIP")) : 0;
     a.skip = env_skip; a.dbg = g_dbg;
+    a.xp_stagger = getenv("GDB_XP_STAGGER") ? atoi(getenv("GDB_XP_STAGGER")) : 0;   // (read per call: the experiment sweeps it inside one process)
+    a.xp_per_rank = device_cus() / 8;   // workgroups of one dispatch rank per XCD: one per CU
 #endif
     hipStream_t st = (hipStream_t)stream_;
     // GDB_PREC_F16 gathers its feature taps from the half-precision copy of the pyramid: made here (a launch of its own on the same

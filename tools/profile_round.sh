@@ -43,7 +43,9 @@ from bench import kernel_source_sha16   # gdb_fused.hip + gdb_internal.h + gdb_o
 sha = kernel_source_sha16()
 tj = dict(res["traffic_bytes"])
 tj["_kernel_source_sha256_16"] = sha
-tj["_source"] = "profiles/$TAG/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, per launch: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; MI355X guide, HBM section)"
+tj["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, per launch: 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes (MI355X guide, HBM section); per key: _sources"
+# the file each key's counters were read from (bench.py's roofline.traffic_source names the one of ITS key: VERDICT r05 item 10)
+tj["_sources"] = {k: "profiles/$TAG/pmc_" + k.rsplit(":", 1)[1] + "/summary.txt (workload " + k.split(":")[0] + ")" for k in res["traffic_bytes"]}
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print("traffic.json written to", out, "- copy it to profiles/traffic.json (the file bench.py reads) together with the summaries")
 PY
