@@ -56,9 +56,13 @@ static size_t conv_floats(int cin, int nt) { return (size_t)((cin + 31) / 32) * 
 struct DecLayout {
     size_t in_w, in_b, blk[DEC_MAX_LAYERS][5] /* conv1, conv2, conv3, fc0, fc2 */, up_w, up_b;
     size_t in_wx, blkx[DEC_MAX_LAYERS][3], up_wx;  // the same convolutions as split-f16 fragments (pack_conv_x), behind the fp32 ones
+    // upscale_factor 4 (bundle_size 4: two up stages, decoder_rdn.py:59-62): the FIRST stage's 64 -> 256 convolution as four 64 -> 64
+    // convolutions, one per sub-pixel of its PixelShuffle (fp32 and split-f16 forms, biases); up_w / up_b then hold the SECOND stage folded
+    // with out_conv.  Zero-sized at upscale_factor 2.
+    size_t u1_w[4], u1_wx[4], u1_b[4];
     size_t total;
 };
-static DecLayout dec_layout(int nlayers) {
+static DecLayout dec_layout(int nlayers, int bundle_size = 2) {
     DecLayout L{};
     size_t o = 0;
     L.in_w = o; o += conv_floats(27, 2);
@@ -79,6 +83,12 @@ static DecLayout dec_layout(int nlayers) {
         L.blkx[b][2] = o; o += conv_floats(128, 2);
     }
     L.up_wx = o; o += conv_floats(64, 1);
+    if (bundle_size == 4)
+        for (int sp = 0; sp < 4; ++sp) {
+            L.u1_w[sp] = o; o += conv_floats(64, 2);
+            L.u1_wx[sp] = o; o += conv_floats(64, 2);
+            L.u1_b[sp] = o; o += 64;
+        }
     L.total = (o + 8 * 128 + 63) / 64 * 64;  // + one tap block: the fp32 conv kernel's weight prefetch runs one tap ahead
     return L;
 }
@@ -124,7 +134,8 @@ static void pack_conv_x(const float* w, int cout, int cin, int nt, float* out) {
 
 static int dec_check(const GdbConfig* cfg, int nlayers) {
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
-    if (cfg->bundle_size != 2) return gdb_fail(GDB_E_BADARG, "the HIP decoder is built for bundle_size 2 (one up stage); got %d", cfg->bundle_size);
+    if (cfg->bundle_size != 2 && cfg->bundle_size != 4)
+        return gdb_fail(GDB_E_BADARG, "the HIP decoder is built for bundle_size 2 (one up stage) and 4 (two); got %d", cfg->bundle_size);
     if (nlayers < 1 || nlayers > DEC_MAX_LAYERS) return gdb_fail(GDB_E_BADARG, "decoder layers %d outside 1..%d", nlayers, DEC_MAX_LAYERS);
     return GDB_OK;
 }
@@ -132,20 +143,22 @@ static int dec_check(const GdbConfig* cfg, int nlayers) {
 extern "C" int gdb_decoder_packed_floats(const GdbConfig* cfg, int32_t num_layers, size_t* out_floats) {
     int rc = dec_check(cfg, num_layers); if (rc) return rc;
     if (!out_floats) return gdb_fail(GDB_E_BADARG, "out_floats is NULL");
-    *out_floats = dec_layout(num_layers).total;
+    *out_floats = dec_layout(num_layers, cfg->bundle_size).total;
     return GDB_OK;
 }
 
 // h_tensors in state-dict order (decoder_rdn.py:55-65): in_conv.weight (64,27,3,3), in_conv.bias, then per block conv1.weight
 // (32,64,3,3), conv2.weight (32,96,3,3), conv3.weight (64,128,3,3), se.fc.0.weight (4,64), se.fc.2.weight (64,4), then
-// up.0.weight (256,64,3,3), up.0.bias (256), out_conv.weight (3,64,1,1), out_conv.bias (3): 2 + 5 num_layers + 4 pointers.
+// up.0.weight (256,64,3,3), up.0.bias (256), [bundle_size 4: up.2.weight (256,64,3,3), up.2.bias (256),] out_conv.weight (3,64,1,1),
+// out_conv.bias (3): 2 + 5 num_layers + 4 (+ 2) pointers.
 extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers, const float* const* t, float* out) {
     int rc = dec_check(cfg, num_layers); if (rc) return rc;
     if (!t || !out) return gdb_fail(GDB_E_BADARG, "NULL pointer");
-    const int n = 2 + 5 * num_layers + 4;
+    const bool up4 = cfg->bundle_size == 4;
+    const int n = 2 + 5 * num_layers + 4 + (up4 ? 2 : 0);
     for (int i = 0; i < n; ++i)
         if (!t[i]) return gdb_fail(GDB_E_BADARG, "decoder tensor %d is NULL", i);
-    const DecLayout L = dec_layout(num_layers);
+    const DecLayout L = dec_layout(num_layers, cfg->bundle_size);
     memset(out, 0, sizeof(float) * L.total);
     const int cin0 = GDB_CFR + GDB_CV;  // 27
     pack_conv16(t[0], DEC_NF, cin0, out + L.in_w);
@@ -164,7 +177,21 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
     }
     // fold: out_conv o PixelShuffle(2) o up.  PixelShuffle: up channel 4 k + s (s = dy*2 + dx) -> feature k of sub-pixel s.
     // folded output channel c = 3 s + o:  W[c][ci][tap] = sum_k Wout[o][k] Wup[4k + s][ci][tap],  b[c] = sum_k Wout[o][k] bup[4k + s] + bout[o]
+    // (upscale_factor 4: there is no non-linearity anywhere in `up` (decoder_rdn.py:59-62, :79-80), so the LAST stage folds with out_conv
+    // exactly as the single stage of upscale_factor 2 does; the first stage stays a convolution - four of them, one per sub-pixel)
     const float* wup = t[n - 4]; const float* bup = t[n - 3]; const float* wout = t[n - 2]; const float* bout = t[n - 1];
+    if (up4) {
+        const float* w0 = t[n - 6]; const float* b0 = t[n - 5];
+        std::vector<float> ws((size_t)DEC_NF * DEC_NF * 9);
+        for (int sp = 0; sp < 4; ++sp) {   // PixelShuffle: conv channel 4 k + sp -> feature k of sub-pixel sp = dy * 2 + dx
+            for (int k = 0; k < DEC_NF; ++k) {
+                memcpy(ws.data() + (size_t)k * DEC_NF * 9, w0 + (size_t)(4 * k + sp) * DEC_NF * 9, sizeof(float) * DEC_NF * 9);
+                out[L.u1_b[sp] + k] = b0[4 * k + sp];
+            }
+            pack_conv16(ws.data(), DEC_NF, DEC_NF, out + L.u1_w[sp]);
+            pack_conv_x(ws.data(), DEC_NF, DEC_NF, 2, out + L.u1_wx[sp]);
+        }
+    }
     std::vector<float> wf((size_t)12 * DEC_NF * 9);
     for (int s = 0; s < 4; ++s)
         for (int o = 0; o < 3; ++o) {
@@ -192,8 +219,8 @@ extern "C" int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers
 #ifndef DEC_SEG
 #define DEC_SEG 128   // segments per workgroup of k_se_gate's first stage (256x320, 2,560 segments: 16 / 32 / 64 / 128 / 256 -> 18.4 / 10.8 / 7.9 / 6.6 / 7.8 us: the last arriver's serial tail)
 #endif
-struct DecWs { size_t P[3], Y, T, part, part2, gate, count, total; int nseg, ngrp; };
-static DecWs dec_ws(int B, int H, int W) {
+struct DecWs { size_t P[3], Y, T, part, part2, gate, count, X, U, total; int nseg, ngrp; };   // X, U: upscale_factor 4 only (the blocks' output with the last gate applied; the first up stage's (2H, 2W, 64) map)
+static DecWs dec_ws(int B, int H, int W, int bundle_size = 2) {
     DecWs w{};
     const size_t n = (size_t)B * H * W;
     w.nseg = H * ((W + 31) / 32);
@@ -206,6 +233,11 @@ static DecWs dec_ws(int B, int H, int W) {
     w.part2 = o; o = align_up(o + sizeof(float) * (size_t)B * w.ngrp * DEC_NF, 256);
     w.gate = o; o = align_up(o + sizeof(float) * (size_t)B * DEC_NF, 256);
     w.count = o; o = align_up(o + sizeof(unsigned) * (size_t)B, 256);
+    w.X = o; w.U = o;
+    if (bundle_size == 4) {
+        o = align_up(o + sizeof(float) * n * DEC_NF, 256);
+        w.U = o; o = align_up(o + sizeof(float) * 4 * n * DEC_NF, 256);
+    }
     w.total = o;
     return w;
 }
@@ -213,7 +245,7 @@ extern "C" int gdb_decoder_workspace_bytes(const GdbConfig* cfg, const GdbFrame*
     int rc = gdb_check_cfg(cfg); if (rc) return rc;
     if (!shape || !out_bytes) return gdb_fail(GDB_E_BADARG, "NULL pointer");
     if (shape->B < 1 || shape->H < 1 || shape->W < 1) return gdb_fail(GDB_E_SHAPE, "non-positive bundle map");
-    *out_bytes = dec_ws(shape->B, shape->H, shape->W).total;
+    *out_bytes = dec_ws(shape->B, shape->H, shape->W, cfg->bundle_size).total;
     return GDB_OK;
 }
 
@@ -224,6 +256,7 @@ struct ConvArgs {
     const float* w; const float* bias;
     float* out; int out_stride, out_off, cout, relu;
     float* rgb;                     // folded up stage: (B,3,2H,2W) NCHW, channel c = 3 s + o of sub-pixel s = dy*2 + dx
+    int up2, up_dy, up_dx;          // first up stage of upscale_factor 4: output pixel (y, x) is written at (2y + up_dy, 2x + up_dx) of a (2H, 2W) map
     // squeeze-excitation folded into the consumer (FUSE kernels; decoder_rdn.py:40,78): the staged input is x = in + fT * gate (+ fS),
     // all (pixels, 64); the workgroup's own pixels of x are also written to fX (the next block's P) when fX is set
     const float* fT; const float* fgate; const float* fS; float* fX;
@@ -457,7 +490,8 @@ __global__ void __launch_bounds__(256, 5) k_conv16(ConvArgs a) {
         for (int q = 0; q < NR; ++q) {
             const int y = y0 + wrow + q;
             if (y >= a.H) continue;
-            const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+            const size_t pix = a.up2 ? ((size_t)b * 2 * a.H + 2 * y + a.up_dy) * (2 * (size_t)a.W) + 2 * x + a.up_dx
+                                     : (size_t)b * a.H * a.W + (size_t)y * a.W + x;
             F4 v = acc[p][q];
             if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (a.rgb) {  // folded up stage: channel c = 3 s + o -> rgb[b][o][2y + (s >> 1)][2x + (s & 1)]
@@ -598,7 +632,8 @@ __global__ void __launch_bounds__(256) k_conv3x3x(ConvArgs a) {
             }
         }
         if (!valid) continue;
-        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+        const size_t pix = a.up2 ? ((size_t)b * 2 * a.H + 2 * y + a.up_dy) * (2 * (size_t)a.W) + 2 * x + a.up_dx
+                                 : (size_t)b * a.H * a.W + (size_t)y * a.W + x;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = 32 * t + 8 * g + 4 * h;
@@ -673,6 +708,22 @@ __global__ void __launch_bounds__(256) k_se_gate(const float* __restrict__ part,
     if (threadIdx.x == 0) count[b] = 0u;
 }
 
+// upscale_factor 4: the dense blocks' output with the last squeeze-excitation gate and the global residual applied,
+// x = P + T * gate + S (decoder_rdn.py:40, :78), as its own (tiny: the b = 4 bundle map is a sixteenth of the image) element-wise pass -
+// the four sub-pixel convolutions of the first up stage all read it.  Rounded as the fused apply of the bundle_size 2 path rounds.
+__global__ void __launch_bounds__(256) k_apply_gate(const float* __restrict__ P, const float* __restrict__ T, const float* __restrict__ gate,
+                                                    const float* __restrict__ S, float* __restrict__ X, size_t npix_per_item, int B) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of 64 channels: 16 per pixel
+    if (i >= (size_t)B * npix_per_item * 16) return;
+    const size_t pix = i >> 4; const int c4 = (int)(i & 15) * 4;
+    const int b = (int)(pix / npix_per_item);
+    const F4 p = *(const F4*)(P + pix * DEC_NF + c4), t = *(const F4*)(T + pix * DEC_NF + c4), g = *(const F4*)(gate + (size_t)b * DEC_NF + c4);
+    const F4 sres = *(const F4*)(S + pix * DEC_NF + c4);
+    F4 v = p + t * g;
+    v = v + sres;
+    *(F4*)(X + pix * DEC_NF + c4) = v;
+}
+
 // ---- entry ---------------------------------------------------------------------------------------------------------------
 static hipError_t launch_conv(const ConvArgs& a, hipStream_t st) {   // 64 output channels
     const size_t lds = sizeof(float) * (size_t)(2 + 2) * DEC_PX * DEC_CHS;
@@ -716,11 +767,12 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
     if (B > 256) return gdb_fail(GDB_E_SHAPE, "decoder batch %d > 256", B);
     const int Q = 3 * cfg->bundle_size * cfg->bundle_size + GDB_CFR + GDB_CV, n_rgb = 3 * cfg->bundle_size * cfg->bundle_size;
     if (ld_bundle_feat < Q) return gdb_fail(GDB_E_SHAPE, "bundle_feat row stride %d < %d channels", ld_bundle_feat, Q);
-    const DecWs ws = dec_ws(B, H, W);
+    const bool up4 = cfg->bundle_size == 4;
+    const DecWs ws = dec_ws(B, H, W, cfg->bundle_size);
     if (ws_bytes < ws.total) return gdb_fail(GDB_E_WORKSPACE, "decoder workspace %zu B < required %zu B", ws_bytes, ws.total);
-    if ((size_t)H * W * (size_t)(ld_bundle_feat > DEC_NF ? ld_bundle_feat : DEC_NF) >= ((size_t)1 << 30))
+    if ((size_t)H * W * (up4 ? 4 : 1) * (size_t)(ld_bundle_feat > DEC_NF ? ld_bundle_feat : DEC_NF) >= ((size_t)1 << 30))
         return gdb_fail(GDB_E_SHAPE, "bundle map too large for the decoder's 32-bit staging byte offsets");
-    const DecLayout L = dec_layout(num_layers);
+    const DecLayout L = dec_layout(num_layers, cfg->bundle_size);
     hipStream_t st = (hipStream_t)stream_;
     float* Pbuf[3] = {(float*)((char*)d_ws + ws.P[0]), (float*)((char*)d_ws + ws.P[1]), (float*)((char*)d_ws + ws.P[2])};
     auto Px = [&](int b) -> float* { return b == 0 ? Pbuf[0] : Pbuf[1 + ((b - 1) & 1)]; };   // the input x of dense block b
@@ -743,7 +795,9 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
             attr_done.fetch_or(1ull << dev);
         }
     }
+    int cH = H, cW = W;   // the map the next convolution runs on ((2H, 2W) for the last stage of upscale_factor 4)
     auto conv = [&](ConvArgs a, int nt) -> hipError_t {
+        const int H = cH, W = cW;
         a.B = B; a.H = H; a.W = W; a.tilesX = (W + 31) / 32;
         a.nchunk = (a.cin + 31) / 32;
         if (!a.in2) a.split = a.nchunk;
@@ -784,10 +838,32 @@ extern "C" int gdb_decode(const GdbConfig* cfg, const GdbFrame* shape, const flo
                            d_packed + L.blk[b][3], d_packed + L.blk[b][4], part2, count, gate);
         CK(hipGetLastError());
     }
-    {   // out_conv(PixelShuffle(up(x + shallow))) as one folded 64 -> 12 convolution on x = x_{L-1} + x3 * gate + shallow   :40,78-80
+    if (!up4) {   // out_conv(PixelShuffle(up(x + shallow))) as one folded 64 -> 12 convolution on x = x_{L-1} + x3 * gate + shallow   :40,78-80
         ConvArgs a{};
         a.in = Px(num_layers - 1); a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
         a.fT = T; a.fgate = gate; a.fS = Px(0);
+        a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
+        a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
+        CK(conv(a, 1));
+    } else {
+        // upscale_factor 4 (bundle_size 4; decoder_rdn.py:59-62): x = x_{L-1} + x3 * gate + shallow as its own pass, the first up stage as
+        // four 64 -> 64 convolutions (one per sub-pixel of its PixelShuffle) into the (2H, 2W, 64) map U, then the second stage folded with
+        // out_conv as ONE 64 -> 12 convolution on U, written pixel-shuffled to the (4H, 4W) image - no non-linearity anywhere in between.
+        float* X = (float*)((char*)d_ws + ws.X); float* U = (float*)((char*)d_ws + ws.U);
+        const size_t npix = (size_t)H * W;
+        hipLaunchKernelGGL(k_apply_gate, dim3((unsigned)(((size_t)B * npix * 16 + 255) / 256)), dim3(256), 0, st, Px(num_layers - 1), T, gate, Px(0), X, npix, B);
+        CK(hipGetLastError());
+        for (int sp = 0; sp < 4; ++sp) {
+            ConvArgs a{};
+            a.in = X; a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
+            a.w = d_packed + (split ? L.u1_wx[sp] : L.u1_w[sp]); a.bias = d_packed + L.u1_b[sp];
+            a.out = U; a.out_stride = DEC_NF; a.out_off = 0; a.cout = DEC_NF; a.relu = 0;
+            a.up2 = 1; a.up_dy = sp >> 1; a.up_dx = sp & 1;
+            CK(conv(a, 2));
+        }
+        cH = 2 * H; cW = 2 * W;
+        ConvArgs a{};
+        a.in = U; a.in_stride = DEC_NF; a.in_off = 0; a.cin = DEC_NF;
         a.w = d_packed + (split ? L.up_wx : L.up_w); a.bias = d_packed + L.up_b;
         a.cout = 12; a.relu = 0; a.rgb = d_rgb_c;
         CK(conv(a, 1));

@@ -386,9 +386,12 @@ class HotPathEngine:
         keys = ["in_conv.weight", "in_conv.bias"]
         for i in range(num_layers):
             keys += [f"blocks.{i}.conv1.weight", f"blocks.{i}.conv2.weight", f"blocks.{i}.conv3.weight", f"blocks.{i}.se.fc.0.weight", f"blocks.{i}.se.fc.2.weight"]
-        keys += ["up.0.weight", "up.0.bias", "out_conv.weight", "out_conv.bias"]
+        keys += ["up.0.weight", "up.0.bias"]
+        if self.cfg.bundle_size == 4:   # upscale_factor 4: a second up stage (decoder_rdn.py:59-62: nn.Sequential indices 0 and 2 are the convolutions)
+            keys += ["up.2.weight", "up.2.bias"]
+        keys += ["out_conv.weight", "out_conv.bias"]
         cin = self.cfg.feat_dim + 3 + self.cfg.voxel_dim
-        expect = {"in_conv.weight": (64, cin, 3, 3), "up.0.weight": (256, 64, 3, 3), "out_conv.weight": (3, 64, 1, 1)}
+        expect = {"in_conv.weight": (64, cin, 3, 3), "up.0.weight": (256, 64, 3, 3), "up.2.weight": (256, 64, 3, 3), "out_conv.weight": (3, 64, 1, 1)}
         arrs, ptrs = [], (C.c_void_p * len(keys))()
         for i, k in enumerate(keys):
             v = state[prefix + k]

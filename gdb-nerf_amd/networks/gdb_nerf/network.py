@@ -55,9 +55,9 @@ class Network(nn.Module):
         self.precision = {"f32": 1, "f16": 0, "f32x": 2}[str(getattr(nrf, "precision", "f32"))]
         # N1: the decoder on the HIP library (fp32 MFMA implicit-GEMM convolutions, channel-last, reading bundle_feat in place);
         # False keeps the PyTorch-ROCm module.  The HIP decoder takes any number of dense blocks up to 16 (every reference config has 3) and
-        # is built for bundle_size 2 (one up stage, folded with out_conv): b = 4 - which the fused hot path does not take either - keeps
-        # the PyTorch module.
-        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size == 2 and 1 <= int(self.dec_layers) <= 16
+        # bundle_size 2 (one up stage, folded with out_conv) or 4 (two: decoder_rdn.py:59-62 - the first as four sub-pixel convolutions,
+        # the second folded; round 6); b = 1 (no up stage) keeps the PyTorch module.
+        self.hip_decoder = bool(getattr(nrf, "hip_decoder", True)) and self.b_size in (2, 4) and 1 <= int(self.dec_layers) <= 16
         # Multi-GPU: "rows" = when torch.distributed is initialised, every rank renders one contiguous strip of
         # bundle-map rows of the frame and ONE all-gather of the packed rows (RCCL over xGMI) leaves the whole bundle map on every
         # rank; decoder and merge then run replicated (the decoder's squeeze-excitation takes a global mean over the image,

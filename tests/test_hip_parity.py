@@ -1144,7 +1144,9 @@ def test_prepare_pyr16_without_source_images_is_refused():
     rc = eng.lib.gdb_prepare_ex(C.byref(eng.cfg), C.byref(f), None, _lib.PREP_PYR16, eng._ws.data_ptr(), eng._ws.numel(), None)
     f.d_src_images = saved
     assert rc == -1 and "d_src_images" in eng.lib.gdb_last_error().decode()
-    assert eng.lib.gdb_prepare_ex(C.byref(eng.cfg), C.byref(f), None, 8, eng._ws.data_ptr(), eng._ws.numel(), None) == -1   # unknown flag bit
+    assert eng.lib.gdb_prepare_ex(C.byref(eng.cfg), C.byref(f), None, 64, eng._ws.data_ptr(), eng._ws.numel(), None) == -1   # unknown flag bit
+    rc = eng.lib.gdb_prepare_rows(C.byref(eng.cfg), C.byref(f), None, _lib.PREP_STRIP_REACH | _lib.PREP_STRIP_WHOLE, 0, 4, eng._ws.data_ptr(), eng._ws.numel(), None)
+    assert rc == -1 and "exclude" in eng.lib.gdb_last_error().decode()
 
 
 @pytest.mark.parametrize("prec", [1, 0, 2], ids=["f32", "f16", "f32x"])

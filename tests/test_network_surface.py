@@ -62,7 +62,8 @@ def test_decoder_gating_and_packed_weight_invalidation(monkeypatch):
     from gdb_nerf_amd.networks.gdb_nerf import network as netmod
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "17"])).hip_decoder is False
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "4"])).hip_decoder is True
-    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "4"])).hip_decoder is False
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "4"])).hip_decoder is True    # (two up stages: on the HIP library since round 6)
+    assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.bundle_size", "1"])).hip_decoder is False   # (no up stage: the PyTorch module)
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.dec_layers", "3"])).hip_decoder is True
     assert make_network(make_cfg("configs/dtu_eval.yaml", ["nerf.hip_decoder", "False"])).hip_decoder is False
 
@@ -191,13 +192,13 @@ def test_network_forward_matches_reference_on_the_other_branches(f7, fixture, ho
 
 def test_bundle_size_4_network_loads_the_reference_checkpoint():
     """configs/dtu_pretrain.yaml:33 "bundle_size: 2  # 4 for 4*4": the 4x4 configuration (vol_levels [0, 0], vol_scales [0.125, 0.25])
-    builds with the reference's checkpoint layout - a decoder with two up stages (decoder_rdn.py:52-63) - and keeps the PyTorch
-    decoder (the HIP decoder is built for one up stage).  Fixture F7d: the reference's own Network under that configuration."""
+    builds with the reference's checkpoint layout - a decoder with two up stages (decoder_rdn.py:52-63), which the HIP decoder takes
+    since round 6.  Fixture F7d: the reference's own Network under that configuration."""
     fx = load_golden("F7d_network_bundle4")
     net = make_network(make_cfg("configs/dtu_eval.yaml", [str(x) for x in fx["opts"]])).eval()
     missing = net.load_state_dict(_state_dict(fx), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
-    assert net.b_size == 4 and net.feat_level == 0 and net.hip_decoder is False and net.hot_path == "fused"
+    assert net.b_size == 4 and net.feat_level == 0 and net.hip_decoder is True and net.hot_path == "fused"   # (the HIP decoder takes upscale_factor 4 since round 6)
 
 
 @pytest.mark.gpu
@@ -205,7 +206,7 @@ def test_bundle_size_4_network_loads_the_reference_checkpoint():
 def test_network_forward_bundle_size_4_matches_reference(hot_path):
     """A bundle_size 4 config goes through Network.forward on the HIP library: since round 6 on the FUSED entries (the dense list kernel
     on the bundles' centre rays + k_bundle_colours; until then the operator-mirror chain), "mirrors" = the PyTorch-facing operator
-    classes; merge runs on the HIP kernel (k_merge<4>), the two-stage decoder on PyTorch-ROCm.  Against the reference's own forward
+    classes; merge runs on the HIP kernel (k_merge<4>), the two-stage decoder on the HIP library too (round 6).  Against the reference's own forward
     (F7d; network.py:31-34, 145-182).  F7d overrides fpn.feat_dims to [16, 16, 8] so that the level the 4 x 4 bundle map reads has the 16
     channels the kernels are built for; the reference's literal 4 x 4 setup (feat_dims [32, 16, 8] -> 32 channels at level 0) is refused
     by gdb_check_cfg (feat_dim != 16) on every HIP path - stated in DESIGN.md 0, unpinned here."""

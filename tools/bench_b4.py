@@ -61,6 +61,25 @@ for b in (2, 4):
     rec["op_prepare_ms"] = timed(lambda: eng.prepare(frame))
     res[f"b{b}"] = rec
     del eng, frame, s, rfd, vox, sigma, feat
+# the b = 4 network's decoder (Decoder(upscale_factor=4): two up stages, decoder_rdn.py:59-62) on the HIP library (round 6) against the
+# PyTorch-ROCm module it kept until then, on the 128 x 160 bundle map of a 512 x 640 frame
+try:
+    from gdb_nerf_amd.networks.gdb_nerf.decoder_rdn import Decoder
+    torch.manual_seed(0)
+    dec = Decoder(27, 3, num_feats=64, num_layers=3, upscale_factor=4).eval().to(dev)
+    frame = to_dev(synthetic.make_frame(Ho, Wo, V=V, bundle_size=4, scene="dtu", seed=0), dev)
+    eng = HotPathEngine(bundle_size=4, max_num_samples=S, is_adaptive=True, device=dev)
+    eng.load_weights(w); eng.reuse_outputs = True; eng.prepare(frame)
+    eng.load_decoder_weights({k: v.detach() for k, v in dec.state_dict().items()}, 3)
+    packed = eng.render_packed().clone()
+    x = packed[:, 48:75].view(1, Ho // 4, Wo // 4, 27).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        want = dec(x)
+        res["b4_decoder"] = {"hip_fp32_ms": timed(lambda: eng.decode(packed, precision=1)), "hip_split_f16_ms": timed(lambda: eng.decode(packed, precision=2)),
+                             "torch_miopen_ms": timed(lambda: dec(x)),
+                             "max_abs_err_vs_torch": float((eng.decode(packed, precision=1) - want).abs().max()), "output_scale": float(want.abs().max())}
+except Exception as ex:
+    res["b4_decoder"] = {"error": repr(ex)}
 f2 = res["b2"].get("fused_ns_per_ray")
 if f2:
     res["b4_mirrors_over_b2_fused_per_ray"] = res["b4"]["mirrors_ns_per_ray"] / f2
