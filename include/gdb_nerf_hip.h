@@ -380,13 +380,16 @@ int gdb_merge_packed(const GdbConfig* cfg, const GdbFrame* shape, const float* d
 /* Decoder.forward, networks/gdb_nerf/decoder_rdn.py:44-81 (instantiated at network.py:51 as Decoder(C_f+3+C_v, 3, num_feats=64,
  * num_layers=nerf.dec_layers, upscale_factor=b); called at network.py:170-175): in_conv, num_layers ResidualDenseBlocks with
  * squeeze-excitation, up-conv + PixelShuffle, 1x1 out_conv — 3x3 convolutions as implicit GEMMs on fp32 MFMA, channel-last.
- * bundle_size 2 only (one up stage); num_layers 1 .. 16 (two activation buffers alternate between the blocks).
+ * bundle_size 2 (upscale_factor 2: one up stage) and, since round 6, 4 (two up stages, decoder_rdn.py:59-62); bundle_size 1 (no up stage)
+ * is refused; num_layers 1 .. 16 (two activation buffers alternate between the blocks).
  *
  * gdb_pack_decoder_weights: h_tensors in state-dict order — in_conv.weight (64,C_in,3,3), in_conv.bias, then per block
  * conv1.weight (32,64,3,3), conv2.weight (32,96,3,3), conv3.weight (64,128,3,3), se.fc.0.weight (4,64), se.fc.2.weight (64,4),
- * then up.0.weight (256,64,3,3), up.0.bias, out_conv.weight (3,64,1,1), out_conv.bias: 2 + 5 num_layers + 4 host pointers.
- * The up stage is folded into one 64 -> 12 convolution on the host (no non-linearity sits between up-conv, PixelShuffle and
- * out_conv). */
+ * then up.0.weight (256,64,3,3), up.0.bias, [bundle_size 4: up.2.weight (256,64,3,3), up.2.bias,] out_conv.weight (3,64,1,1),
+ * out_conv.bias: 2 + 5 num_layers + 4 (+ 2) host pointers.
+ * The LAST up stage is folded with out_conv into one 64 -> 12 convolution on the host (no non-linearity sits between up-conv,
+ * PixelShuffle and out_conv); at bundle_size 4 the first up stage runs as four 64 -> 64 convolutions, one per sub-pixel of its
+ * PixelShuffle, into a (2H, 2W, 64) map in the workspace, on which the folded stage then runs: d_rgb_c is (B, 3, 4H, 4W). */
 int gdb_decoder_packed_floats(const GdbConfig* cfg, int32_t num_layers, size_t* out_floats);
 int gdb_pack_decoder_weights(const GdbConfig* cfg, int32_t num_layers, const float* const* h_tensors, float* h_out);
 /* shape needs B, H, W (the bundle map). */
