@@ -275,7 +275,7 @@ class HotPathEngine:
         out = (C.c_int32 * 4)()
         precision = self.precision if precision is None else precision
         _lib.check(self.lib.gdb_render_info(C.byref(self.cfg), C.byref(f), int(precision), int(row_begin), int(f.H if row_end is None else row_end), out))
-        sched = int(self.schedule) or int(out[1])
+        sched = int(out[1]) if self.cfg.bundle_size != 2 else (int(self.schedule) or int(out[1]))   # (bundle_size 1 / 4: the one schedule, whatever the engine's setting)
         return {"fused": int(out[0]), "schedule": int(out[1]), "plan_built_by_prepare": int(out[2]), "launches": int(out[3]),
                 "kernel": {0: None, 1: "k_render_fused", 2: "k_render_solo", 3: "k_render_dense", 4: "k_render_flat"}[sched if out[0] else 0]}
 

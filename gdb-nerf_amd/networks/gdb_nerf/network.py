@@ -188,11 +188,11 @@ class Network(nn.Module):
         if self.hot_path == "fused":
             c = lambda t: t.contiguous().float()
             eng = self._get_engine(src_images.device)
-            # a rank of a row-sharded forward plans its own strip of bundle-map rows only (the pyramid stays whole: a strip's samples
-            # project anywhere into the source views)
+            # a rank of a row-sharded forward plans its own strip of bundle-map rows only, and - for frames large enough for the bound's
+            # launch to pay - builds only the strip's reach of the pyramids (gdb_prepare_rows; any bundle size)
             dist = self._dist()
             rows = None
-            if dist is not None and self.b_size == 2:
+            if dist is not None:
                 from ...parallel import row_strip
                 rows = row_strip(H, dist.get_rank(), dist.get_world_size())
             # N3: the kernel resamples the colour channels itself (no torch.cat / F.interpolate of the source images)
