@@ -393,7 +393,7 @@ def _softplus(x: np.ndarray) -> np.ndarray:
 
 
 def nerf_mlp(w: Dict[str, np.ndarray], vox_feat: np.ndarray, rgbs_feat_dir: np.ndarray,
-             feat_dim: int = 16, viewdir_agg: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+             feat_dim: int = 16, viewdir_agg: bool = True, return_blend_weights: bool = False):
     """Radiance / density MLP over V source views.  State-dict names as in nerf.py:20-56.
 
     nerf.py:98 the last feat_dim+3+4 channels feed the MLP; :69-71 view-direction add;
@@ -421,6 +421,8 @@ def nerf_mlp(w: Dict[str, np.ndarray], vox_feat: np.ndarray, rgbs_feat_dir: np.n
     bw = _softmax0(_relu(_linear(w, "weight.2", _relu(_linear(w, "weight.0", wf)))))
     blended = np.sum(x_in[..., :-4] * bw, axis=0, dtype=F32)
     feat = np.concatenate((blended, _relu(_linear(w, "feat_head.0", x))), axis=-1).astype(F32)
+    if return_blend_weights:   # (V, N, 1): the softmax over views of nerf.py:108-109, for tests of the bundle_size 1 / 4 decomposition
+        return sigma.astype(F32), feat, bw.astype(F32)
     return sigma.astype(F32), feat
 
 
